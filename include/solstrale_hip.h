@@ -1,0 +1,247 @@
+/*
+ * solstrale_hip.h -- C ABI of the MI355X (gfx950) path-tracing library `libsolstrale_hip.so`.
+ *
+ * This is the drop-in boundary for ONE hot path of DanielPettersson/Solstrale-Rust: the body of the
+ * per-pass row loop of `Renderer::render` (reference src/renderer/mod.rs:241-291), i.e. everything under
+ * `Renderer::ray_color` (src/renderer/mod.rs:164-206): BVH closest hit (src/hittable/), material scatter
+ * and pdf importance sampling (src/material/mod.rs, src/pdf.rs), camera rays (src/camera.rs:77-89) and the
+ * per-pixel accumulation (src/renderer/mod.rs:268,361-365).
+ *
+ * The reference has no FFI of its own on this path: the host (Rust `Renderer`, or the C++
+ * mirror in solstrale-rust_amd/host/) keeps scene loading, the BVH builder (src/hittable/bvh.rs:61-162),
+ * Camera::new (src/camera.rs:47-74), the pass loop, progress reporting and post-processing; it flattens its
+ * `Hittables` tree into the POD arrays below and calls sol_scene_create / sol_render / sol_read.
+ *
+ * Every struct mirrors the fields of a reference type, in f64 exactly as the reference holds them; the
+ * library converts to its fp32 device layout on upload (DESIGN.md "Data layout in HBM").
+ *
+ * All functions return 0 on success, a negative SOL_E* code otherwise; sol_last_error() gives the
+ * thread-local message. Nothing here aborts the process. No torch types appear in any signature.
+ */
+#ifndef SOLSTRALE_HIP_H
+#define SOLSTRALE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOL_ABI_VERSION 1
+
+/* ---- error codes ---------------------------------------------------------------------------------- */
+#define SOL_OK 0
+#define SOL_EINVAL (-1)    /* malformed description / argument                                         */
+#define SOL_ENOLIGHT (-2)  /* "Scene should have at least one light" (src/renderer/mod.rs:143-147)      */
+#define SOL_EDEVICE (-3)   /* HIP runtime error / no GPU                                               */
+#define SOL_EDEPTH (-4)    /* BVH deeper than the traversal stack supports                             */
+#define SOL_ENOMEM (-5)
+
+/* ---- child / primitive references ------------------------------------------------------------------
+ * A 32-bit reference: kind in bits 31..28, index into the array of that kind in bits 27..0.
+ * Mirrors `BvhItem::{Node, Leaf(Box<Hittables>), None}` (src/hittable/bvh.rs:21-25) with the leaf's
+ * `Hittables` variant (src/hittable/mod.rs:47-61) made explicit. A nested `Bvh` held in a Leaf is
+ * inlined by the flattener as SOL_REF_NODE (Bvh::hit is the same function, so this is exact). */
+#define SOL_REF_NONE 0u
+#define SOL_REF_NODE 1u
+#define SOL_REF_SPHERE 2u
+#define SOL_REF_QUAD 3u
+#define SOL_REF_TRIANGLE 4u
+#define SOL_REF_MEDIUM 5u
+#define SOL_REF_KIND(r) ((uint32_t)(r) >> 28)
+#define SOL_REF_INDEX(r) ((uint32_t)(r) & 0x0FFFFFFFu)
+#define SOL_MAKE_REF(kind, index) ((((uint32_t)(kind)) << 28) | ((uint32_t)(index) & 0x0FFFFFFFu))
+
+/* Axis-aligned box, `Aabb{x,y,z: Interval{min,max}}` (src/geo/mod.rs:39-46): xmin,xmax,ymin,ymax,zmin,zmax */
+typedef struct SolAabb {
+  double v[6];
+} SolAabb;
+
+/* `Bvh{left,right,b_box}` (src/hittable/bvh.rs:14-18) */
+typedef struct SolBvhNode {
+  SolAabb bbox;
+  uint32_t left;  /* SOL_MAKE_REF(...) */
+  uint32_t right; /* SOL_MAKE_REF(...) */
+} SolBvhNode;
+
+/* `Sphere{center,radius,mat,b_box}` (src/hittable/sphere.rs:15-20) */
+typedef struct SolSphere {
+  double center[3];
+  double radius;
+  SolAabb bbox;
+  int32_t material;
+  uint32_t dfs_index; /* position in the depth-first leaf order of the world tree (tie rule) */
+} SolSphere;
+
+/* `Quad{q,u,v,normal,d,w,mat,b_box,area}` (src/hittable/quad.rs:19-29) */
+typedef struct SolQuad {
+  double q[3], u[3], v[3], normal[3];
+  double d;
+  double w[3];
+  double area;
+  SolAabb bbox;
+  int32_t material;
+  uint32_t dfs_index;
+} SolQuad;
+
+/* `Triangle{v0,v0v1,v0v2,uv0..2,normal,tangent,bi_tangent,mat,b_box,area}` (src/hittable/triangle.rs:14-27) */
+typedef struct SolTriangle {
+  double v0[3], v0v1[3], v0v2[3];
+  double normal[3], tangent[3], bi_tangent[3];
+  double area;
+  float uv0[2], uv1[2], uv2[2]; /* `Uv{f32,f32}` (src/geo/mod.rs:15-20) */
+  SolAabb bbox;
+  int32_t material;
+  uint32_t dfs_index;
+} SolTriangle;
+
+/* `ConstantMedium{boundary,negative_inverse_density,phase_function}` (src/hittable/constant_medium.rs:14-19) */
+typedef struct SolMedium {
+  uint32_t boundary; /* reference to the boundary hittable (its own sub-tree of nodes/prims)            */
+  int32_t material;  /* the Isotropic phase function                                                    */
+  double negative_inverse_density;
+  SolAabb bbox;
+  uint32_t dfs_index;
+  uint32_t _pad;
+} SolMedium;
+
+/* `Materials` (src/material/mod.rs:134-150) */
+#define SOL_MAT_LAMBERTIAN 0
+#define SOL_MAT_METAL 1
+#define SOL_MAT_DIELECTRIC 2
+#define SOL_MAT_DIFFUSE_LIGHT 3
+#define SOL_MAT_ISOTROPIC 4
+#define SOL_MAT_BLEND 5
+typedef struct SolMaterial {
+  int32_t kind;
+  int32_t albedo_tex; /* Lambertian/Metal/Dielectric.albedo, DiffuseLight.tex, Isotropic.tex; -1 for Blend */
+  int32_t normal_tex; /* `normal: Option<Textures>`; -1 = None                                          */
+  int32_t m1, m2;     /* Blend.material_1 / material_2 (indices into materials), else -1                 */
+  int32_t _pad;
+  /* Metal.fuzz | Dielectric.index_of_refraction | Blend.blend_factor |
+   * DiffuseLight.attenuation_factor with NaN standing for `None` (src/material/mod.rs:320-340) */
+  double param;
+} SolMaterial;
+
+/* `Textures::{SolidColor(Vec3), ImageMap{image,max_x,max_y}}` (src/material/texture.rs:26-33,101,128-133) */
+#define SOL_TEX_SOLID 0
+#define SOL_TEX_IMAGE 1
+typedef struct SolTexture {
+  int32_t kind;
+  uint32_t width, height; /* image only                                                                */
+  uint32_t _pad;
+  uint64_t texel_offset; /* byte offset of the first RGB8 texel in SolSceneDesc.texels                 */
+  double rgb[3];         /* solid colour                                                               */
+} SolTexture;
+
+/* `Camera{origin,lower_left_corner,horizontal,vertical,u,v,lens_radius}` (src/camera.rs:35-43),
+ * produced on the host by Camera::new (src/camera.rs:47-74). */
+typedef struct SolCamera {
+  double origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+  double lens_radius;
+} SolCamera;
+
+/* `Shaders` (src/renderer/shader.rs:33-44) */
+#define SOL_SHADER_PATH_TRACING 0
+#define SOL_SHADER_ALBEDO 1
+#define SOL_SHADER_NORMAL 2
+#define SOL_SHADER_SIMPLE 3
+
+typedef struct SolSceneDesc {
+  uint32_t abi_version; /* SOL_ABI_VERSION */
+  uint32_t width, height; /* RenderConfig.width/height (src/renderer/mod.rs:26-30)                      */
+  uint32_t shader_kind;   /* SOL_SHADER_*                                                               */
+  uint32_t max_depth;     /* PathTracingShader.max_depth (src/renderer/shader.rs:48-50)                 */
+  uint32_t root;          /* reference to `Scene.world` (src/renderer/mod.rs:63-72)                     */
+  double background[3];   /* Scene.background_color                                                     */
+  SolCamera camera;
+
+  const SolBvhNode* nodes;      uint32_t n_nodes;
+  const SolSphere* spheres;     uint32_t n_spheres;
+  const SolQuad* quads;         uint32_t n_quads;
+  const SolTriangle* triangles; uint32_t n_triangles;
+  const SolMedium* mediums;     uint32_t n_mediums;
+  const SolMaterial* materials; uint32_t n_materials;
+  const SolTexture* textures;   uint32_t n_textures;
+  const uint8_t* texels;        uint64_t n_texel_bytes;
+  /* `Renderer.lights` = world.get_lights() in depth-first order (src/renderer/mod.rs:126,141;
+   * src/hittable/bvh.rs:186-193): references to light primitives */
+  const uint32_t* lights;       uint32_t n_lights;
+} SolSceneDesc;
+
+/* Counters of the last instrumented render (sol_render_counted); zero otherwise. Definitions are the
+ * ones SURVEY.md 8d / DESIGN.md use for algorithmic bytes. */
+typedef struct SolStats {
+  uint64_t samples;       /* ray_color(primary,0,0) evaluations                                         */
+  uint64_t rays;          /* world closest-hit queries (src/renderer/mod.rs:165), any depth             */
+  uint64_t node_visits;   /* device BVH nodes fetched (64 B each)                                       */
+  uint64_t sphere_tests, quad_tests, triangle_tests; /* primitive hit evaluations incl. light pdf tests */
+  uint64_t shades;        /* material scatter evaluations                                               */
+  uint64_t texel_fetches;
+  uint64_t max_stack;     /* deepest traversal stack use                                                */
+} SolStats;
+
+typedef struct SolScene SolScene; /* opaque handle: owns device memory, stream; one host thread at a time */
+
+/* Number of visible HIP devices (0 if none / no driver). */
+int sol_device_count(void);
+
+/* Validates and deep-copies `desc` onto HIP device `device` (caller may free its arrays on return).
+ * Replaces the buffer/camera/pool set-up of Renderer::render (src/renderer/mod.rs:223-234) and carries
+ * Renderer::new's "Scene should have at least one light" check (src/renderer/mod.rs:143-147, SOL_ENOLIGHT). */
+int sol_scene_create(const SolSceneDesc* desc, int device, SolScene** out);
+void sol_scene_destroy(SolScene* scene);
+
+/* Image-tile sharding for one-process-per-GPU runs (no reference analogue). The image is cut
+ * into 8x8-pixel blocks, block b (row-major) belongs to rank b % world. Each rank accumulates only its own
+ * blocks in a compact buffer of sol_accum_floats() floats: [local_block][py][px][rgb]. Default rank 0/1. */
+int sol_scene_set_partition(SolScene* scene, int rank, int world);
+
+/* Compact accumulator (device memory, fp32 sums over samples). By default the handle owns it; a caller that
+ * wants to hand it to a collective (torch.distributed / RCCL) may bind its own device buffer instead. */
+size_t sol_accum_floats(const SolScene* scene);
+void* sol_accum_ptr(SolScene* scene);
+int sol_scene_bind_accum(SolScene* scene, void* device_ptr, size_t n_floats);
+/* Use the caller's hipStream_t for all work of this handle (NULL = the handle's own stream). */
+int sol_scene_set_stream(SolScene* scene, void* hip_stream);
+
+/* Zero the accumulator. */
+int sol_clear(SolScene* scene);
+
+/* Enqueue samples [first_sample, first_sample + n_samples) of every pixel this rank owns; their colours are
+ * ADDED to the accumulator (sums, not means: src/renderer/mod.rs:361-365, src/util/rgb_color.rs:21-35).
+ * Asynchronous. Replaces the row tasks of one or more passes (src/renderer/mod.rs:241-291). `seed` keys the
+ * counter-based RNG that replaces src/random.rs; the result is a pure function of (scene, seed, pixel,
+ * sample index) and independent of the partition. */
+int sol_render(SolScene* scene, uint32_t first_sample, uint32_t n_samples, uint64_t seed);
+/* Same, with instrumentation counters enabled (slower; fills sol_stats). */
+int sol_render_counted(SolScene* scene, uint32_t first_sample, uint32_t n_samples, uint64_t seed);
+int sol_sync(SolScene* scene);
+
+/* Blocks; writes the full-image fp32 sums, W*H*3 floats, row 0 = image TOP (row index (H-1-y),
+ * src/renderer/mod.rs:261). Pixels owned by other ranks are written as 0 when world > 1. */
+int sol_read(SolScene* scene, float* rgb_sum);
+
+/* Rank-0 side of the multi-GPU gather: `gathered` is device memory holding world compact buffers back to
+ * back (rank r at offset r * sol_accum_floats()), as produced by an RCCL gather; writes the row-major image
+ * (W*H*3 floats, row 0 = top) to device memory `image`. */
+int sol_unpermute(SolScene* scene, const void* gathered_dev, int world, void* image_dev);
+
+/* Device-side Nop post-processor: sums -> (/spp, sqrt, clamp, *256) -> RGB8, the arithmetic of
+ * src/util/rgb_color.rs:14-35 via src/post/nop.rs:19-34. `image_dev` is W*H*3 floats row-major (device),
+ * `rgb8_host` receives W*H*3 bytes. */
+int sol_tonemap_rgb8(SolScene* scene, const void* image_dev, uint32_t num_samples, uint8_t* rgb8_host);
+
+int sol_stats(const SolScene* scene, SolStats* out);
+
+/* Sizes of the device records, for the algorithmic-bytes formula: node, sphere, quad, triangle
+ * intersect records, shading record, material record (bytes). */
+int sol_record_sizes(uint32_t out[6]);
+
+const char* sol_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOLSTRALE_HIP_H */

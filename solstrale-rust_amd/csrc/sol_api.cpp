@@ -1,0 +1,536 @@
+// sol_api.cpp -- implementation of the C ABI (include/solstrale_hip.h): validation of the flattened scene,
+// conversion to the fp32 device layout (sol_types.h), upload, and launches of the kernels in sol_kernels.hip.
+// There is NO CPU fallback: without a HIP device every compute entry point fails with SOL_EDEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/solstrale_hip.h"
+#include "sol_launch.h"
+#include "sol_types.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(SOL_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+struct Box {
+  float v[6];
+};
+const float F_INF = std::numeric_limits<float>::infinity();
+Box empty_box() { return Box{{F_INF, -F_INF, F_INF, -F_INF, F_INF, -F_INF}}; }
+Box cast_box(const SolAabb& b) {
+  Box r;
+  for (int i = 0; i < 6; ++i) r.v[i] = (float)b.v[i];
+  return r;
+}
+
+// Converts the reference-shaped tree (own box per node) into device nodes (child boxes in the parent).
+struct TreeBuilder {
+  const SolSceneDesc& d;
+  std::vector<DNode> nodes;
+  std::vector<int32_t> dev_index;  // desc node -> device node (-1 not yet / collapsed)
+  std::vector<uint8_t> on_path;
+  uint32_t max_depth = 0;
+  std::string error;
+
+  explicit TreeBuilder(const SolSceneDesc& desc) : d(desc), dev_index(desc.n_nodes, -1), on_path(desc.n_nodes, 0) {}
+
+  bool prim_box(uint32_t ref, Box& box) {
+    uint32_t k = SOL_REF_KIND(ref), i = SOL_REF_INDEX(ref);
+    switch (k) {
+      case SOL_REF_SPHERE: if (i >= d.n_spheres) return false; box = cast_box(d.spheres[i].bbox); return true;
+      case SOL_REF_QUAD: if (i >= d.n_quads) return false; box = cast_box(d.quads[i].bbox); return true;
+      case SOL_REF_TRIANGLE: if (i >= d.n_triangles) return false; box = cast_box(d.triangles[i].bbox); return true;
+      case SOL_REF_MEDIUM: if (i >= d.n_mediums) return false; box = cast_box(d.mediums[i].bbox); return true;
+    }
+    return false;
+  }
+
+  // Returns the device reference of `ref` and the box the parent must test for it.
+  bool resolve(uint32_t ref, uint32_t depth, uint32_t& out_ref, Box& out_box) {
+    uint32_t k = SOL_REF_KIND(ref), i = SOL_REF_INDEX(ref);
+    if (k == SOL_REF_NONE) { out_ref = SOL_MAKE_REF(SOL_REF_NONE, 0); out_box = empty_box(); return true; }
+    if (k != SOL_REF_NODE) {
+      if (!prim_box(ref, out_box)) { error = "primitive reference out of range"; return false; }
+      out_ref = ref;
+      return true;
+    }
+    if (i >= d.n_nodes) { error = "node reference out of range"; return false; }
+    if (on_path[i]) { error = "cycle in BVH"; return false; }
+    if (depth > 4000) { error = "BVH nesting deeper than 4000"; return false; }
+    const SolBvhNode& n = d.nodes[i];
+    const uint32_t lk = SOL_REF_KIND(n.left), rk = SOL_REF_KIND(n.right);
+    if (rk == SOL_REF_NONE && lk != SOL_REF_NONE && lk != SOL_REF_NODE) {
+      // `new_bvh` of a single primitive (bvh.rs:85-90): Bvh{Leaf(a), None, box(a)}. The parent tests the node's box and
+      // goes straight to the primitive.
+      Box pb;
+      if (!prim_box(n.left, pb)) { error = "primitive reference out of range"; return false; }
+      out_ref = n.left;
+      out_box = cast_box(n.bbox);
+      return true;
+    }
+    if (dev_index[i] >= 0) {  // shared sub-tree
+      out_ref = SOL_MAKE_REF(SOL_REF_NODE, (uint32_t)dev_index[i]);
+      out_box = cast_box(n.bbox);
+      return true;
+    }
+    const uint32_t di = (uint32_t)nodes.size();
+    if (di >= 0x0FFFFFFFu) { error = "too many nodes"; return false; }
+    dev_index[i] = (int32_t)di;
+    nodes.push_back(DNode{});
+    on_path[i] = 1;
+    if (depth + 1 > max_depth) max_depth = depth + 1;
+    uint32_t lr, rr;
+    Box lb, rb;
+    if (!resolve(n.left, depth + 1, lr, lb) || !resolve(n.right, depth + 1, rr, rb)) return false;
+    on_path[i] = 0;
+    DNode& dn = nodes[di];
+    dn.lxmin = lb.v[0]; dn.lxmax = lb.v[1]; dn.lymin = lb.v[2]; dn.lymax = lb.v[3]; dn.lzmin = lb.v[4]; dn.lzmax = lb.v[5];
+    dn.rxmin = rb.v[0]; dn.rxmax = rb.v[1]; dn.rymin = rb.v[2]; dn.rymax = rb.v[3]; dn.rzmin = rb.v[4]; dn.rzmax = rb.v[5];
+    dn.left = lr; dn.right = rr; dn.pad0 = dn.pad1 = 0;
+    out_ref = SOL_MAKE_REF(SOL_REF_NODE, di);
+    out_box = cast_box(n.bbox);
+    return true;
+  }
+};
+
+template <typename T>
+int upload(const std::vector<T>& host, T** dev) {
+  *dev = nullptr;
+  size_t bytes = std::max<size_t>(host.size() * sizeof(T), 64);  // never a null device pointer
+  HIP_TRY(hipMalloc((void**)dev, bytes));
+  HIP_TRY(hipMemset(*dev, 0, bytes));
+  if (!host.empty()) HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  return SOL_OK;
+}
+
+}  // namespace
+
+struct SolScene {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  DevScene S{};
+  // owned device buffers
+  DNode* nodes = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
+  DSphere* spheres = nullptr; DMedium* mediums = nullptr; DMat* mats = nullptr; DTex* texs = nullptr;
+  uint8_t* texels = nullptr; uint32_t* lights = nullptr;
+  float* acc_own = nullptr; float* acc = nullptr; size_t acc_floats = 0;
+  float* partial = nullptr; size_t partial_floats = 0;
+  float* image = nullptr;  // W*H*3 scratch for sol_read
+  uint8_t* rgb8 = nullptr;
+  uint32_t* work = nullptr; uint32_t* spill = nullptr; size_t spill_words = 0;
+  DevCounters* counters = nullptr;
+  SolStats stats{};
+  bool has_medium = false;
+  uint32_t tree_depth = 0;
+  int rank = 0, world = 1;
+  uint32_t blocks_x = 0, blocks_y = 0, n_local_blocks = 0;
+  int n_cu = 0;
+};
+
+static int set_partition(SolScene* s, int rank, int world) {
+  if (world < 1 || rank < 0 || rank >= world) return fail(SOL_EINVAL, "bad partition %d/%d", rank, world);
+  s->rank = rank; s->world = world;
+  const uint32_t nb = s->blocks_x * s->blocks_y;
+  s->n_local_blocks = (nb + (uint32_t)world - 1u - (uint32_t)rank) / (uint32_t)world;  // blocks b with b % world == rank
+  // every rank's compact buffer has the size of rank 0's (the largest) so that a gather has equal counts
+  const uint32_t max_blocks = (nb + (uint32_t)world - 1u) / (uint32_t)world;
+  size_t floats = (size_t)max_blocks * 64u * 3u;
+  if (floats != s->acc_floats || !s->acc) {
+    if (s->acc_own) { hipFree(s->acc_own); s->acc_own = nullptr; }
+    HIP_TRY(hipMalloc((void**)&s->acc_own, std::max<size_t>(floats * sizeof(float), 64)));
+    HIP_TRY(hipMemset(s->acc_own, 0, std::max<size_t>(floats * sizeof(float), 64)));
+    s->acc = s->acc_own;
+    s->acc_floats = floats;
+  }
+  return SOL_OK;
+}
+
+extern "C" {
+
+const char* sol_last_error(void) { return g_err.c_str(); }
+
+int sol_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sol_record_sizes(uint32_t out[6]) {
+  out[0] = sizeof(DNode); out[1] = sizeof(DSphere); out[2] = sizeof(DQuad); out[3] = sizeof(DTri);
+  out[4] = sizeof(DTriShade); out[5] = sizeof(DMat);
+  return SOL_OK;
+}
+
+void sol_scene_destroy(SolScene* s) {
+  if (!s) return;
+  hipSetDevice(s->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  void* ptrs[] = {s->nodes, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
+                  s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (s->own_stream) hipStreamDestroy(s->own_stream);
+  delete s;
+}
+
+int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
+  if (!d || !out) return fail(SOL_EINVAL, "null argument");
+  *out = nullptr;
+  if (d->abi_version != SOL_ABI_VERSION) return fail(SOL_EINVAL, "abi_version %u, expected %u", d->abi_version, SOL_ABI_VERSION);
+  if (d->width < 2 || d->height < 2 || (uint64_t)d->width * d->height > 0x3FFFFFFFull) return fail(SOL_EINVAL, "bad image size %ux%u", d->width, d->height);
+  if (d->shader_kind > SOL_SHADER_SIMPLE) return fail(SOL_EINVAL, "bad shader kind %u", d->shader_kind);
+  if ((d->n_nodes && !d->nodes) || (d->n_spheres && !d->spheres) || (d->n_quads && !d->quads) ||
+      (d->n_triangles && !d->triangles) || (d->n_mediums && !d->mediums) || (d->n_materials && !d->materials) ||
+      (d->n_textures && !d->textures) || (d->n_texel_bytes && !d->texels) || (d->n_lights && !d->lights))
+    return fail(SOL_EINVAL, "null array with non-zero count");
+  // Renderer::new: "Scene should have at least one light" (src/renderer/mod.rs:143-147)
+  if (d->n_lights == 0) return fail(SOL_ENOLIGHT, "Scene should have at least one light");
+  if (d->n_texel_bytes > 0xFFFFFFF0ull) return fail(SOL_EINVAL, "more than 4 GiB of texels");
+
+  // ---- materials / textures ----
+  std::vector<DTex> texs(d->n_textures);
+  for (uint32_t i = 0; i < d->n_textures; ++i) {
+    const SolTexture& t = d->textures[i];
+    DTex& o = texs[i];
+    std::memset(&o, 0, sizeof o);
+    o.kind = t.kind;
+    if (t.kind == SOL_TEX_IMAGE) {
+      if (!t.width || !t.height || t.texel_offset + (uint64_t)t.width * t.height * 3 > d->n_texel_bytes)
+        return fail(SOL_EINVAL, "texture %u: image outside texel buffer", i);
+      o.w = t.width; o.h = t.height; o.offset = (uint32_t)t.texel_offset;
+    } else if (t.kind == SOL_TEX_SOLID) {
+      o.r = (float)t.rgb[0]; o.g = (float)t.rgb[1]; o.b = (float)t.rgb[2];
+    } else {
+      return fail(SOL_EINVAL, "texture %u: bad kind %d", i, t.kind);
+    }
+  }
+  auto tex_ok = [&](int32_t id, bool optional) { return (optional && id < 0) || (id >= 0 && (uint32_t)id < d->n_textures); };
+  std::vector<DMat> mats(d->n_materials);
+  for (uint32_t i = 0; i < d->n_materials; ++i) {
+    const SolMaterial& m = d->materials[i];
+    DMat& o = mats[i];
+    std::memset(&o, 0, sizeof o);
+    o.kind = m.kind; o.albedo = m.albedo_tex; o.normal = m.normal_tex; o.m1 = m.m1; o.m2 = m.m2;
+    o.param = (float)m.param;
+    if (std::isnan(m.param)) o.flags |= DMAT_PARAM_NONE;
+    switch (m.kind) {
+      case SOL_MAT_LAMBERTIAN: case SOL_MAT_METAL: case SOL_MAT_DIELECTRIC:
+        if (!tex_ok(m.albedo_tex, false) || !tex_ok(m.normal_tex, true)) return fail(SOL_EINVAL, "material %u: bad texture id", i);
+        break;
+      case SOL_MAT_DIFFUSE_LIGHT: case SOL_MAT_ISOTROPIC:
+        if (!tex_ok(m.albedo_tex, false)) return fail(SOL_EINVAL, "material %u: bad texture id", i);
+        o.normal = -1;
+        break;
+      case SOL_MAT_BLEND:
+        if (m.m1 < 0 || m.m2 < 0 || (uint32_t)m.m1 >= d->n_materials || (uint32_t)m.m2 >= d->n_materials || (uint32_t)m.m1 == i || (uint32_t)m.m2 == i)
+          return fail(SOL_EINVAL, "material %u: bad blend children", i);
+        break;
+      default: return fail(SOL_EINVAL, "material %u: bad kind %d", i, m.kind);
+    }
+  }
+  // NEEDS_UV: any image texture reachable from the material (Blend children included; bounded iteration)
+  for (int pass = 0; pass < 16; ++pass)
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+      DMat& o = mats[i];
+      bool need = false;
+      if (o.kind == SOL_MAT_BLEND) need = (mats[o.m1].flags | mats[o.m2].flags) & DMAT_NEEDS_UV;
+      else need = (o.albedo >= 0 && texs[o.albedo].kind == SOL_TEX_IMAGE) || (o.normal >= 0 && texs[o.normal].kind == SOL_TEX_IMAGE);
+      if (need) o.flags |= DMAT_NEEDS_UV;
+    }
+  auto mat_ok = [&](int32_t id) { return id >= 0 && (uint32_t)id < d->n_materials; };
+
+  // ---- primitives (plain casts) ----
+  std::vector<DTri> tris(d->n_triangles);
+  std::vector<DTriShade> tshade(d->n_triangles);
+  for (uint32_t i = 0; i < d->n_triangles; ++i) {
+    const SolTriangle& t = d->triangles[i];
+    if (!mat_ok(t.material)) return fail(SOL_EINVAL, "triangle %u: bad material", i);
+    DTri& o = tris[i];
+    o.v0x = (float)t.v0[0]; o.v0y = (float)t.v0[1]; o.v0z = (float)t.v0[2];
+    o.e1x = (float)t.v0v1[0]; o.e1y = (float)t.v0v1[1]; o.e1z = (float)t.v0v1[2];
+    o.e2x = (float)t.v0v2[0]; o.e2y = (float)t.v0v2[1]; o.e2z = (float)t.v0v2[2];
+    o.dfs = t.dfs_index; o.mat = t.material; o.pad = 0;
+    DTriShade& s = tshade[i];
+    s.nx = (float)t.normal[0]; s.ny = (float)t.normal[1]; s.nz = (float)t.normal[2]; s.area = (float)t.area;
+    s.tx = (float)t.tangent[0]; s.ty = (float)t.tangent[1]; s.tz = (float)t.tangent[2];
+    s.bx = (float)t.bi_tangent[0]; s.by = (float)t.bi_tangent[1]; s.bz = (float)t.bi_tangent[2];
+    s.u0 = t.uv0[0]; s.v0 = t.uv0[1]; s.u1 = t.uv1[0]; s.v1 = t.uv1[1]; s.u2 = t.uv2[0]; s.v2 = t.uv2[1];
+  }
+  std::vector<DQuad> quads(d->n_quads);
+  for (uint32_t i = 0; i < d->n_quads; ++i) {
+    const SolQuad& q = d->quads[i];
+    if (!mat_ok(q.material)) return fail(SOL_EINVAL, "quad %u: bad material", i);
+    DQuad& o = quads[i];
+    o.nx = (float)q.normal[0]; o.ny = (float)q.normal[1]; o.nz = (float)q.normal[2]; o.d = (float)q.d;
+    o.qx = (float)q.q[0]; o.qy = (float)q.q[1]; o.qz = (float)q.q[2]; o.dfs = q.dfs_index;
+    o.wx = (float)q.w[0]; o.wy = (float)q.w[1]; o.wz = (float)q.w[2]; o.mat = q.material;
+    o.ux = (float)q.u[0]; o.uy = (float)q.u[1]; o.uz = (float)q.u[2]; o.area = (float)q.area;
+    o.vx = (float)q.v[0]; o.vy = (float)q.v[1]; o.vz = (float)q.v[2]; o.pad = 0.f;
+  }
+  std::vector<DSphere> spheres(d->n_spheres);
+  for (uint32_t i = 0; i < d->n_spheres; ++i) {
+    const SolSphere& s = d->spheres[i];
+    if (!mat_ok(s.material)) return fail(SOL_EINVAL, "sphere %u: bad material", i);
+    DSphere& o = spheres[i];
+    o.cx = (float)s.center[0]; o.cy = (float)s.center[1]; o.cz = (float)s.center[2]; o.radius = (float)s.radius;
+    o.dfs = s.dfs_index; o.mat = s.material; o.pad0 = o.pad1 = 0;
+  }
+
+  // ---- tree ----
+  TreeBuilder tb(*d);
+  uint32_t root_ref;
+  Box root_box;
+  if (!tb.resolve(d->root, 0, root_ref, root_box)) return fail(SOL_EINVAL, "world: %s", tb.error.c_str());
+  if (SOL_REF_KIND(root_ref) == SOL_REF_NONE) return fail(SOL_EINVAL, "world is empty");
+  const uint32_t world_depth = tb.max_depth;
+  std::vector<DMedium> mediums(d->n_mediums);
+  uint32_t medium_depth = 0;
+  for (uint32_t i = 0; i < d->n_mediums; ++i) {
+    const SolMedium& m = d->mediums[i];
+    if (!mat_ok(m.material)) return fail(SOL_EINVAL, "medium %u: bad material", i);
+    if (i >= 0x1000u) return fail(SOL_EINVAL, "more than 4096 constant mediums");
+    DMedium& o = mediums[i];
+    std::memset(&o, 0, sizeof o);
+    tb.max_depth = 0;
+    uint32_t bref;
+    Box bb;
+    if (!tb.resolve(m.boundary, 0, bref, bb)) return fail(SOL_EINVAL, "medium %u boundary: %s", i, tb.error.c_str());
+    if (SOL_REF_KIND(bref) == SOL_REF_MEDIUM || SOL_REF_KIND(bref) == SOL_REF_NONE) return fail(SOL_EINVAL, "medium %u: unsupported boundary", i);
+    medium_depth = std::max(medium_depth, tb.max_depth);
+    o.boundary = bref; o.mat = m.material; o.nid = (float)m.negative_inverse_density; o.dfs = m.dfs_index;
+    o.bxmin = bb.v[0]; o.bxmax = bb.v[1]; o.bymin = bb.v[2]; o.bymax = bb.v[3]; o.bzmin = bb.v[4]; o.bzmax = bb.v[5];
+  }
+  // a medium inside a medium boundary would recurse in the device search: reject (never built by the reference's scenes)
+  for (uint32_t i = 0; i < d->n_mediums; ++i) {
+    std::vector<uint32_t> stk{mediums[i].boundary};
+    while (!stk.empty()) {
+      uint32_t r = stk.back(); stk.pop_back();
+      if (SOL_REF_KIND(r) == SOL_REF_MEDIUM) return fail(SOL_EINVAL, "medium %u: nested ConstantMedium in a boundary is unsupported", i);
+      if (SOL_REF_KIND(r) == SOL_REF_NODE) { stk.push_back(tb.nodes[SOL_REF_INDEX(r)].left); stk.push_back(tb.nodes[SOL_REF_INDEX(r)].right); }
+    }
+  }
+  const uint32_t tree_depth = world_depth + medium_depth + 2;
+  if (tree_depth > SOL_LDS_STACK + SOL_SPILL_STACK) return fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", tree_depth, SOL_LDS_STACK + SOL_SPILL_STACK);
+
+  // ---- lights ----
+  std::vector<uint32_t> lights(d->lights, d->lights + d->n_lights);
+  for (uint32_t i = 0; i < d->n_lights; ++i) {
+    uint32_t k = SOL_REF_KIND(lights[i]), x = SOL_REF_INDEX(lights[i]);
+    bool ok = (k == SOL_REF_SPHERE && x < d->n_spheres) || (k == SOL_REF_QUAD && x < d->n_quads) || (k == SOL_REF_TRIANGLE && x < d->n_triangles);
+    if (!ok) return fail(SOL_EINVAL, "light %u: not a sphere/quad/triangle reference", i);
+  }
+
+  // ---- device ----
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SOL_EDEVICE, "no HIP device available");
+  if (device < 0 || device >= ndev) return fail(SOL_EDEVICE, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  SolScene* s = new SolScene();
+  s->device = device;
+  struct Cleanup { SolScene* s; bool keep = false; ~Cleanup() { if (!keep) sol_scene_destroy(s); } } cleanup{s};
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  s->n_cu = prop.multiProcessorCount;
+  HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  s->stream = s->own_stream;
+  int rc;
+  if ((rc = upload(tb.nodes, &s->nodes)) || (rc = upload(tris, &s->tris)) || (rc = upload(tshade, &s->tri_shade)) ||
+      (rc = upload(quads, &s->quads)) || (rc = upload(spheres, &s->spheres)) || (rc = upload(mediums, &s->mediums)) ||
+      (rc = upload(mats, &s->mats)) || (rc = upload(texs, &s->texs)) || (rc = upload(lights, &s->lights)))
+    return rc;
+  std::vector<uint8_t> texels(d->texels, d->texels + d->n_texel_bytes);
+  if ((rc = upload(texels, &s->texels))) return rc;
+  HIP_TRY(hipMalloc((void**)&s->work, 64));
+  HIP_TRY(hipMalloc((void**)&s->counters, sizeof(DevCounters)));
+  HIP_TRY(hipMemset(s->counters, 0, sizeof(DevCounters)));
+  HIP_TRY(hipMalloc((void**)&s->image, (size_t)d->width * d->height * 3 * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&s->rgb8, (size_t)d->width * d->height * 3));
+
+  DevScene& S = s->S;
+  S.nodes = s->nodes; S.tris = s->tris; S.tri_shade = s->tri_shade; S.quads = s->quads; S.spheres = s->spheres;
+  S.mediums = s->mediums; S.mats = s->mats; S.texs = s->texs; S.texels = s->texels; S.lights = s->lights;
+  S.n_lights = d->n_lights;
+  S.root = root_ref;
+  S.rxmin = root_box.v[0]; S.rxmax = root_box.v[1]; S.rymin = root_box.v[2]; S.rymax = root_box.v[3];
+  S.rzmin = root_box.v[4]; S.rzmax = root_box.v[5];
+  S.width = d->width; S.height = d->height; S.shader = d->shader_kind; S.max_depth = d->max_depth;
+  S.bgx = (float)d->background[0]; S.bgy = (float)d->background[1]; S.bgz = (float)d->background[2];
+  const SolCamera& c = d->camera;
+  S.cam = DCamera{(float)c.origin[0], (float)c.origin[1], (float)c.origin[2],
+                  (float)c.lower_left_corner[0], (float)c.lower_left_corner[1], (float)c.lower_left_corner[2],
+                  (float)c.horizontal[0], (float)c.horizontal[1], (float)c.horizontal[2],
+                  (float)c.vertical[0], (float)c.vertical[1], (float)c.vertical[2],
+                  (float)c.u[0], (float)c.u[1], (float)c.u[2], (float)c.v[0], (float)c.v[1], (float)c.v[2],
+                  (float)c.lens_radius};
+  s->has_medium = d->n_mediums > 0;
+  s->tree_depth = tree_depth;
+  s->blocks_x = (d->width + SOL_TILE - 1) / SOL_TILE;
+  s->blocks_y = (d->height + SOL_TILE - 1) / SOL_TILE;
+  if ((rc = set_partition(s, 0, 1))) return rc;
+  cleanup.keep = true;
+  *out = s;
+  return SOL_OK;
+}
+
+int sol_scene_set_partition(SolScene* s, int rank, int world) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  bool bound = s->acc != s->acc_own;
+  int rc = set_partition(s, rank, world);
+  if (rc == SOL_OK && bound) g_err = "partition changed: bound accumulator dropped";
+  return rc;
+}
+
+size_t sol_accum_floats(const SolScene* s) { return s ? s->acc_floats : 0; }
+void* sol_accum_ptr(SolScene* s) { return s ? s->acc : nullptr; }
+
+int sol_scene_bind_accum(SolScene* s, void* p, size_t n_floats) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  if (!p) { s->acc = s->acc_own; return SOL_OK; }
+  if (n_floats < s->acc_floats) return fail(SOL_EINVAL, "bound accumulator too small: %zu < %zu floats", n_floats, s->acc_floats);
+  s->acc = (float*)p;
+  return SOL_OK;
+}
+
+int sol_scene_set_stream(SolScene* s, void* stream) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->stream = stream ? (hipStream_t)stream : s->own_stream;
+  return SOL_OK;
+}
+
+int sol_clear(SolScene* s) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemsetAsync(s->acc, 0, s->acc_floats * sizeof(float), s->stream));
+  return SOL_OK;
+}
+
+static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool count) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  if (n == 0) return SOL_OK;
+  if ((uint64_t)first + n > 0xFFFFFFFFull) return fail(SOL_EINVAL, "sample range overflows 32 bits");
+  HIP_TRY(hipSetDevice(s->device));
+  RenderParams P{};
+  P.first_sample = first; P.n_samples = n;
+  P.n_chunks = (n + SOL_CHUNK - 1) / SOL_CHUNK;
+  P.rank = (uint32_t)s->rank; P.world = (uint32_t)s->world;
+  P.n_local_blocks = s->n_local_blocks; P.blocks_x = s->blocks_x;
+  P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
+  const uint64_t items = (uint64_t)P.n_chunks * P.n_local_blocks * 64u;
+  if (items > 0xFFFF0000ull) return fail(SOL_EINVAL, "too many work items in one call (%llu): split the sample range", (unsigned long long)items);
+  P.n_items = (uint32_t)items;
+  if (P.n_items == 0) return SOL_OK;
+  const int bpc = sol_render_blocks_per_cu(count, s->has_medium);
+  uint32_t grid = (uint32_t)(s->n_cu * bpc);
+  const uint32_t need_blocks = (P.n_items + SOL_WG - 1) / SOL_WG;
+  if (grid > need_blocks) grid = need_blocks;
+  P.total_threads = grid * SOL_WG;
+  // spill stack only when the tree can out-grow the LDS stack
+  size_t spill_words = s->tree_depth > SOL_LDS_STACK ? (size_t)P.total_threads * (s->tree_depth - SOL_LDS_STACK) : 16;
+  if (spill_words > s->spill_words) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->spill) hipFree(s->spill);
+    s->spill = nullptr;
+    HIP_TRY(hipMalloc((void**)&s->spill, spill_words * sizeof(uint32_t)));
+    s->spill_words = spill_words;
+  }
+  const size_t slots3 = (size_t)P.n_local_blocks * 64u * 3u;
+  if (P.n_chunks > 1) {
+    size_t need = slots3 * P.n_chunks;
+    if (need > s->partial_floats) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      if (s->partial) hipFree(s->partial);
+      s->partial = nullptr;
+      HIP_TRY(hipMalloc((void**)&s->partial, need * sizeof(float)));
+      s->partial_floats = need;
+    }
+    // padding pixels of edge blocks are never written: keep them zero
+    if ((s->S.width % SOL_TILE) || (s->S.height % SOL_TILE)) HIP_TRY(hipMemsetAsync(s->partial, 0, need * sizeof(float), s->stream));
+  }
+  HIP_TRY(hipMemsetAsync(s->work, 0, sizeof(uint32_t), s->stream));
+  if (count) HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(DevCounters), s->stream));
+  HIP_TRY(sol_launch_render(s->S, P, s->acc, s->partial, s->work, s->spill, s->counters, grid, count, s->has_medium, s->stream));
+  if (P.n_chunks > 1) HIP_TRY(sol_launch_resolve(s->acc, s->partial, (uint32_t)slots3, P.n_chunks, s->stream));
+  if (count) {
+    DevCounters c;
+    HIP_TRY(hipMemcpyAsync(&c, s->counters, sizeof c, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->stats.samples = c.samples; s->stats.rays = c.rays; s->stats.node_visits = c.node_visits;
+    s->stats.sphere_tests = c.sphere_tests; s->stats.quad_tests = c.quad_tests; s->stats.triangle_tests = c.triangle_tests;
+    s->stats.shades = c.shades; s->stats.texel_fetches = c.texel_fetches; s->stats.max_stack = c.max_stack;
+  }
+  return SOL_OK;
+}
+
+int sol_render(SolScene* s, uint32_t first, uint32_t n, uint64_t seed) { return render_impl(s, first, n, seed, false); }
+int sol_render_counted(SolScene* s, uint32_t first, uint32_t n, uint64_t seed) { return render_impl(s, first, n, seed, true); }
+
+int sol_sync(SolScene* s) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return SOL_OK;
+}
+
+int sol_read(SolScene* s, float* rgb_sum) {
+  if (!s || !rgb_sum) return fail(SOL_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(sol_launch_unpermute(s->acc, s->image, s->S.width, s->S.height, s->blocks_x, (uint32_t)s->world, (uint32_t)s->rank,
+                               s->acc_floats, s->stream));
+  HIP_TRY(hipMemcpyAsync(rgb_sum, s->image, (size_t)s->S.width * s->S.height * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return SOL_OK;
+}
+
+int sol_unpermute(SolScene* s, const void* gathered, int world, void* image) {
+  if (!s || !gathered || !image) return fail(SOL_EINVAL, "null argument");
+  if (world != s->world) return fail(SOL_EINVAL, "world %d differs from the scene's partition (%d)", world, s->world);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(sol_launch_unpermute((const float*)gathered, (float*)image, s->S.width, s->S.height, s->blocks_x, (uint32_t)world,
+                               0xFFFFFFFFu, s->acc_floats, s->stream));
+  return SOL_OK;
+}
+
+int sol_tonemap_rgb8(SolScene* s, const void* image, uint32_t spp, uint8_t* out) {
+  if (!s || !image || !out || spp == 0) return fail(SOL_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  const uint32_t n = s->S.width * s->S.height * 3;
+  HIP_TRY(sol_launch_tonemap((const float*)image, s->rgb8, n, spp, s->stream));
+  HIP_TRY(hipMemcpyAsync(out, s->rgb8, n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return SOL_OK;
+}
+
+int sol_stats(const SolScene* s, SolStats* out) {
+  if (!s || !out) return fail(SOL_EINVAL, "null argument");
+  *out = s->stats;
+  return SOL_OK;
+}
+
+}  // extern "C"

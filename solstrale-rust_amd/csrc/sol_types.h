@@ -1,0 +1,130 @@
+// sol_types.h -- fp32 device records (data layout in HBM; DESIGN.md "Data layout in HBM").
+// Every field is the plain (float) cast of the f64 field of the same name in include/solstrale_hip.h; nothing is
+// re-derived on upload except the child-box placement of DNode (boxes move from a node to its parent).
+#pragma once
+#include <stdint.h>
+
+#define SOL_WG 256          // threads per workgroup = 4 wave64
+#define SOL_LDS_STACK 32    // traversal stack entries per lane kept in LDS (u32 each -> 32 KiB per workgroup)
+#define SOL_SPILL_STACK 96  // further entries per lane in a global spill area (deep trees, nested medium search)
+#define SOL_CHUNK 16        // samples per work item; fixed so that summation order never depends on the partition
+#define SOL_TILE 8          // 8x8-pixel blocks = one wave's worth of adjacent work items
+
+// 64-byte BVH node: the boxes of BOTH children plus their references, so one fetch (4 x dwordx4 per lane)
+// decides both children. Mirrors `Bvh{left,right,b_box}` (src/hittable/bvh.rs:14-18) with b_box hoisted.
+struct __attribute__((aligned(16))) DNode {
+  float lxmin, lxmax, lymin, lymax;
+  float lzmin, lzmax, rxmin, rxmax;
+  float rymin, rymax, rzmin, rzmax;
+  uint32_t left, right, pad0, pad1;  // SOL_MAKE_REF encoding, NODE index = device node index
+};
+static_assert(sizeof(DNode) == 64, "DNode");
+
+// 48-byte triangle intersect record (src/hittable/triangle.rs:14-17 v0, v0v1, v0v2)
+struct __attribute__((aligned(16))) DTri {
+  float v0x, v0y, v0z, e1x;
+  float e1y, e1z, e2x, e2y;
+  float e2z;
+  uint32_t dfs;
+  int32_t mat;
+  uint32_t pad;
+};
+static_assert(sizeof(DTri) == 48, "DTri");
+
+// 64-byte triangle shading record (triangle.rs:18-27 uv0..2, normal, tangent, bi_tangent, area)
+struct __attribute__((aligned(16))) DTriShade {
+  float nx, ny, nz, area;
+  float tx, ty, tz, u0;
+  float bx, by, bz, v0;
+  float u1, v1, u2, v2;
+};
+static_assert(sizeof(DTriShade) == 64, "DTriShade");
+
+// 80-byte quad record (src/hittable/quad.rs:19-29)
+struct __attribute__((aligned(16))) DQuad {
+  float nx, ny, nz, d;
+  float qx, qy, qz;
+  uint32_t dfs;
+  float wx, wy, wz;
+  int32_t mat;
+  float ux, uy, uz, area;
+  float vx, vy, vz, pad;
+};
+static_assert(sizeof(DQuad) == 80, "DQuad");
+
+// 32-byte sphere record (src/hittable/sphere.rs:15-20)
+struct __attribute__((aligned(16))) DSphere {
+  float cx, cy, cz, radius;
+  uint32_t dfs;
+  int32_t mat;
+  uint32_t pad0, pad1;
+};
+static_assert(sizeof(DSphere) == 32, "DSphere");
+
+// constant medium (src/hittable/constant_medium.rs:14-19)
+struct __attribute__((aligned(16))) DMedium {
+  uint32_t boundary;  // device reference of the boundary sub-tree
+  int32_t mat;
+  float nid;  // negative_inverse_density
+  uint32_t dfs;
+  float bxmin, bxmax, bymin, bymax, bzmin, bzmax;  // box of the boundary root (Bvh::hit tests it first)
+  uint32_t pad0, pad1;
+};
+static_assert(sizeof(DMedium) == 48, "DMedium");
+
+// 32-byte material record (src/material/mod.rs:134-150)
+struct __attribute__((aligned(16))) DMat {
+  int32_t kind, albedo, normal, m1;
+  int32_t m2;
+  float param;
+  uint32_t flags;  // bit0: param is None (DiffuseLight.attenuation_factor); bit1: some texture below is an image
+  uint32_t pad;
+};
+static_assert(sizeof(DMat) == 32, "DMat");
+#define DMAT_PARAM_NONE 1u
+#define DMAT_NEEDS_UV 2u
+
+// 32-byte texture record (src/material/texture.rs:101,128-133)
+struct __attribute__((aligned(16))) DTex {
+  int32_t kind;
+  uint32_t w, h, offset;  // offset: byte offset into texels (RGB8)
+  float r, g, b, pad;
+};
+static_assert(sizeof(DTex) == 32, "DTex");
+
+struct DCamera {
+  float ox, oy, oz, llx, lly, llz, hx, hy, hz, vx, vy, vz, ux, uy, uz, wx, wy, wz, lens_radius;
+};
+
+struct DevScene {
+  const DNode* nodes;
+  const DTri* tris;
+  const DTriShade* tri_shade;
+  const DQuad* quads;
+  const DSphere* spheres;
+  const DMedium* mediums;
+  const DMat* mats;
+  const DTex* texs;
+  const uint8_t* texels;
+  const uint32_t* lights;
+  uint32_t n_lights;
+  uint32_t root;                                          // device reference of the world
+  float rxmin, rxmax, rymin, rymax, rzmin, rzmax;         // world root box (Bvh::hit's own b_box test)
+  uint32_t width, height, shader, max_depth;
+  float bgx, bgy, bgz;
+  DCamera cam;
+};
+
+struct RenderParams {
+  uint32_t first_sample, n_samples, n_chunks;
+  uint32_t rank, world;
+  uint32_t n_local_blocks;   // 8x8 blocks owned by this rank
+  uint32_t blocks_x;         // blocks per image row
+  uint32_t seed_lo, seed_hi;
+  uint32_t n_items;          // n_chunks * n_local_blocks * 64
+  uint32_t total_threads;    // grid * SOL_WG (spill stack stride)
+};
+
+struct DevCounters {
+  unsigned long long samples, rays, node_visits, sphere_tests, quad_tests, triangle_tests, shades, texel_fetches, max_stack;
+};

@@ -1,0 +1,10 @@
+"""solstrale_amd -- Python harness over the MI355X path-tracing library (tests/, bench.py).
+
+The product is native: `_build/libsolstrale_hip.so` (hand-written HIP kernels for gfx950 behind the C ABI of
+include/solstrale_hip.h) and `_build/libsolstrale_host.so` (C++ mirror of the reference's host surface). This package only
+binds them with ctypes; it contains no rendering code and no CPU fallback.
+"""
+from . import _abi  # noqa: F401
+from .host import (AlbedoShader, CameraConfig, HostError, NormalShader, PathTracingShader, RenderConfig, RotationX,  # noqa: F401
+                   RotationY, RotationZ, Scale, Scene, SceneBuilder, SimpleShader, Translation)
+from .device import DeviceError, DeviceScene, device_count, record_sizes  # noqa: F401

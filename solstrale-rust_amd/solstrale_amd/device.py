@@ -1,0 +1,103 @@
+"""Thin Python handle over the device C ABI (libsolstrale_hip.so). No compute happens in Python and there is no
+fallback: every call goes to the HIP library and raises if it fails (e.g. SOL_EDEVICE without a GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+class DeviceError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def device_count():
+    return int(_abi.load_hip().sol_device_count())
+
+
+def record_sizes():
+    out = (C.c_uint32 * 6)()
+    _abi.load_hip().sol_record_sizes(out)
+    return dict(zip(("node", "sphere", "quad", "triangle", "triangle_shade", "material"), [int(x) for x in out]))
+
+
+class DeviceScene:
+    """sol_scene_create .. sol_scene_destroy"""
+
+    def __init__(self, scene, device=0):
+        self.lib = _abi.load_hip()
+        self.scene = scene
+        self.h = C.c_void_p()
+        rc = self.lib.sol_scene_create(scene.desc_ptr, device, C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise DeviceError(rc, self.lib.sol_last_error().decode())
+        self.width, self.height = scene.width, scene.height
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DeviceError(rc, self.lib.sol_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.sol_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_partition(self, rank, world):
+        self._chk(self.lib.sol_scene_set_partition(self.h, rank, world))
+
+    def set_stream(self, hip_stream):
+        self._chk(self.lib.sol_scene_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def accum_floats(self):
+        return int(self.lib.sol_accum_floats(self.h))
+
+    def accum_ptr(self):
+        return int(self.lib.sol_accum_ptr(self.h) or 0)
+
+    def bind_accum(self, device_ptr, n_floats):
+        self._chk(self.lib.sol_scene_bind_accum(self.h, C.c_void_p(device_ptr), n_floats))
+
+    def clear(self):
+        self._chk(self.lib.sol_clear(self.h))
+
+    def render(self, first_sample, n_samples, seed, counted=False):
+        f = self.lib.sol_render_counted if counted else self.lib.sol_render
+        self._chk(f(self.h, first_sample, n_samples, seed))
+
+    def sync(self):
+        self._chk(self.lib.sol_sync(self.h))
+
+    def read(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._chk(self.lib.sol_read(self.h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def unpermute(self, gathered_ptr, world, image_ptr):
+        self._chk(self.lib.sol_unpermute(self.h, C.c_void_p(gathered_ptr), world, C.c_void_p(image_ptr)))
+
+    def tonemap_rgb8(self, image_ptr, num_samples):
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        self._chk(self.lib.sol_tonemap_rgb8(self.h, C.c_void_p(image_ptr), num_samples,
+                                            out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def stats(self):
+        st = _abi.SolStats()
+        self._chk(self.lib.sol_stats(self.h, C.byref(st)))
+        return st.as_dict()

@@ -1,0 +1,357 @@
+"""Scene definitions used by tests/ and bench.py.
+
+Two groups:
+  * the reference's own test scenes, restated call for call from tests/scenes.rs (citations per function); they need
+    the reference's texture files, which live as data fixtures under tests/golden/resources/;
+  * the BASELINE.json workloads, which do not exist in the reference and are authored here from the reference's
+    constructors: C1 Cornell box, C2 Cornell + 10 000 spheres, C3 "Sponza-class" procedural atrium (the real
+    sponza.obj is not available offline), all synthetic and deterministic.
+"""
+import math
+import os
+
+import numpy as np
+
+from . import _abi
+from .host import (CameraConfig, RenderConfig, RotationY, SceneBuilder, Translation)
+
+RESOURCES = os.path.join(_abi.ROOT, "tests", "golden", "resources")
+
+
+def load_image(name):
+    from PIL import Image
+    return np.asarray(Image.open(os.path.join(RESOURCES, name)).convert("RGB"), dtype=np.uint8)
+
+
+# ---- deterministic numbers for procedural content (independent of numpy's generators) -----------------------
+def _mix32(x):
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x21F0AAAD) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x735A2D97) & 0xFFFFFFFF
+    x ^= x >> 15
+    return x
+
+
+def counter_uniform(seed, n, stream=0):
+    """n numbers in [0,1): u_i = (mix32(mix32(i + seed*0x9E3779B9) ^ stream*0x85EBCA6B) >> 8) / 2^24."""
+    i = np.arange(n, dtype=np.uint64)
+    h = _mix32(_mix32((i + seed * 0x9E3779B9) & 0xFFFFFFFF) ^ ((stream * 0x85EBCA6B) & 0xFFFFFFFF))
+    return (h >> 8).astype(np.float64) / 16777216.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE workloads
+# ---------------------------------------------------------------------------------------------------------------
+def _cornell_world(b):
+    """RTIOW 'Cornell box' dimensions with the reference's Quad::new / Quad::new_box / DiffuseLight semantics
+    (SURVEY.md 8d): 5 walls + 1 light quad + 2 boxes = 18 quads."""
+    red = b.Lambertian(b.SolidColor(.65, .05, .05))
+    white = b.Lambertian(b.SolidColor(.73, .73, .73))
+    green = b.Lambertian(b.SolidColor(.12, .45, .15))
+    light = b.DiffuseLight(15., 15., 15.)
+    world = [
+        b.Quad((555, 0, 0), (0, 555, 0), (0, 0, 555), green),
+        b.Quad((0, 0, 0), (0, 555, 0), (0, 0, 555), red),
+        b.Quad((343, 554, 332), (-130, 0, 0), (0, 0, -105), light),
+        b.Quad((0, 0, 0), (555, 0, 0), (0, 0, 555), white),
+        b.Quad((555, 555, 555), (-555, 0, 0), (0, 0, -555), white),
+        b.Quad((0, 0, 555), (555, 0, 0), (0, 555, 0), white),
+    ]
+    world += b.new_box((0, 0, 0), (165, 330, 165), white, [RotationY(15.), Translation((265, 0, 295))])
+    world += b.new_box((0, 0, 0), (165, 165, 165), white, [RotationY(-18.), Translation((130, 0, 65))])
+    return world
+
+
+_CORNELL_CAMERA = dict(vertical_fov_degrees=40., aperture_size=0., look_from=(278, 278, -800), look_at=(278, 278, 0),
+                       up=(0, 1, 0))
+
+
+def cornell_box(render_config=None):
+    """C1: Cornell box, 400x400, 50 spp, PathTracingShader(50)."""
+    rc = render_config or RenderConfig(width=400, height=400, samples_per_pixel=50)
+    b = SceneBuilder()
+    world = _cornell_world(b)
+    return b.finish(b.Bvh(world), CameraConfig(**_CORNELL_CAMERA), (0., 0., 0.), rc)
+
+
+def cornell_spheres(render_config=None, n_spheres=10000, seed=1):
+    """C2: Cornell box + n Lambertian spheres, radius U[3,8], centres uniform in the box interior, albedo U[.1,.9]^3."""
+    rc = render_config or RenderConfig(width=1920, height=1080, samples_per_pixel=256)
+    b = SceneBuilder()
+    world = _cornell_world(b)
+    r = 3. + 5. * counter_uniform(seed, n_spheres, 0)
+    c = np.stack([20. + 515. * counter_uniform(seed, n_spheres, 1 + k) for k in range(3)], axis=1)
+    alb = np.stack([.1 + .8 * counter_uniform(seed, n_spheres, 4 + k) for k in range(3)], axis=1)
+    mats = np.array([b.Lambertian(b.SolidColor(*alb[i])) for i in range(n_spheres)], dtype=np.int32)
+    first, n = b.spheres(c, r, mats)
+    world += list(range(first, first + n))
+    return b.finish(b.Bvh(world), CameraConfig(**_CORNELL_CAMERA), (0., 0., 0.), rc)
+
+
+# ---- C3: "Sponza-class" procedural atrium ---------------------------------------------------------------------
+def _grid(f, nu, nv, tile=(1., 1.)):
+    """Tessellates the parametric surface f(u, v) -> (x, y, z), u,v in [0,1], into 2*nu*nv triangles."""
+    u = np.linspace(0., 1., nu + 1)
+    v = np.linspace(0., 1., nv + 1)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    p = np.stack(f(uu, vv), axis=-1)  # (nu+1, nv+1, 3)
+    t = np.stack([uu * tile[0], vv * tile[1]], axis=-1)
+    a, bq, c, d = p[:-1, :-1], p[1:, :-1], p[1:, 1:], p[:-1, 1:]
+    ta, tb, tc, td = t[:-1, :-1], t[1:, :-1], t[1:, 1:], t[:-1, 1:]
+    tri = np.concatenate([np.stack([a, bq, c], axis=2).reshape(-1, 3, 3), np.stack([a, c, d], axis=2).reshape(-1, 3, 3)])
+    uv = np.concatenate([np.stack([ta, tb, tc], axis=2).reshape(-1, 3, 2), np.stack([ta, tc, td], axis=2).reshape(-1, 3, 2)])
+    return tri, uv.astype(np.float32)
+
+
+def _procedural_texture(kind, size, seed):
+    """RGB8 textures (brick / checker / marble-like noise), deterministic."""
+    y, x = np.mgrid[0:size, 0:size].astype(np.float64) / size
+    n = counter_uniform(seed, size * size, 9).reshape(size, size)
+    if kind == 0:  # brick
+        row = np.floor(y * 16)
+        xs = (x * 8 + 0.5 * (row % 2)) % 1.0
+        mortar = (xs < 0.06) | ((y * 16) % 1.0 < 0.1)
+        base = np.stack([0.55 + 0.2 * n, 0.25 + 0.1 * n, 0.18 + 0.08 * n], -1)
+        img = np.where(mortar[..., None], 0.75, base)
+    elif kind == 1:  # checker
+        c = ((np.floor(x * 8) + np.floor(y * 8)) % 2)[..., None]
+        img = c * np.array([0.8, 0.78, 0.7]) + (1 - c) * np.array([0.25, 0.22, 0.2]) + 0.04 * (n[..., None] - .5)
+    else:  # marble-like
+        s = 0.5 + 0.5 * np.sin(40 * x + 12 * np.sin(9 * y + 3 * seed) + 6 * n)
+        img = s[..., None] * np.array([0.75, 0.7, 0.62]) + (1 - s[..., None]) * np.array([0.45, 0.4, 0.38])
+    return np.clip(img * 255., 0, 255).astype(np.uint8)
+
+
+SPONZA_TRIANGLES = 262267
+
+
+def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1024, n_materials=24):
+    """C3 stand-in: an atrium (floor, two-storey walls, galleries, 2x10x2 columns with arches, hanging drapes, partial
+    roof) tessellated to exactly `n_triangles` Lambertian triangles, `n_materials` materials of which 8 carry image
+    textures, one Quad light above the roof opening and a constant sky background."""
+    rc = render_config or RenderConfig(width=1920, height=1080, samples_per_pixel=512)
+    b = SceneBuilder()
+    mats = []
+    for i in range(n_materials):
+        if i < 8:
+            mats.append(b.Lambertian(b.ImageMap(_procedural_texture(i % 3, texture_size, 100 + i))))
+        else:
+            c = 0.25 + 0.6 * counter_uniform(77, 3, i)
+            mats.append(b.Lambertian(b.SolidColor(*c)))
+    L, Wd, Hh = 15.0, 6.0, 12.0  # half length (x), half width (z), height (y)
+    parts = []  # (weight, surface, material index, uv tiling)
+
+    def plane(o, du, dv):
+        o, du, dv = np.array(o, float), np.array(du, float), np.array(dv, float)
+        return lambda u, v: tuple(o[k] + du[k] * u + dv[k] * v for k in range(3))
+
+    parts.append((10., plane((-L, 0, -Wd), (2 * L, 0, 0), (0, 0, 2 * Wd)), 0, (10, 4)))          # floor
+    parts.append((8., plane((-L, 0, -Wd), (2 * L, 0, 0), (0, Hh, 0)), 1, (10, 4)))               # wall z=-W
+    parts.append((8., plane((-L, 0, Wd), (2 * L, 0, 0), (0, Hh, 0)), 1, (10, 4)))                # wall z=+W
+    parts.append((3., plane((-L, 0, -Wd), (0, 0, 2 * Wd), (0, Hh, 0)), 2, (4, 4)))               # end wall x=-L
+    parts.append((3., plane((L, 0, -Wd), (0, 0, 2 * Wd), (0, Hh, 0)), 2, (4, 4)))                # end wall x=+L
+    parts.append((4., plane((-L, 5.5, -Wd), (2 * L, 0, 0), (0, 0, 2.0)), 3, (10, 1)))            # gallery floor -z
+    parts.append((4., plane((-L, 5.5, Wd - 2.0), (2 * L, 0, 0), (0, 0, 2.0)), 3, (10, 1)))       # gallery floor +z
+    parts.append((3., plane((-L, Hh, -Wd), (2 * L, 0, 0), (0, 0, 2.5)), 4, (10, 1)))             # roof strip -z
+    parts.append((3., plane((-L, Hh, Wd - 2.5), (2 * L, 0, 0), (0, 0, 2.5)), 4, (10, 1)))        # roof strip +z
+    col_x = np.linspace(-L + 1.5, L - 1.5, 10)
+    for side in (-1., 1.):
+        for storey in range(2):
+            y0 = 0.0 if storey == 0 else 5.6
+            for i, cx in enumerate(col_x):
+                cz = side * (Wd - 2.0)
+
+                def column(u, v, cx=cx, cz=cz, y0=y0):
+                    r = 0.35 * (1.0 + 0.08 * np.sin(12 * np.pi * u)) * (1.0 - 0.1 * v)
+                    return cx + r * np.cos(2 * np.pi * u), y0 + 4.2 * v, cz + r * np.sin(2 * np.pi * u)
+
+                parts.append((2.2, column, 5 + (i % 3), (2, 3)))
+                if i + 1 < len(col_x):
+                    x1 = col_x[i + 1]
+
+                    def arch(u, v, x0=cx, x1=x1, cz=cz, y0=y0):
+                        ang = np.pi * u
+                        xm, rad = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
+                        return xm - rad * np.cos(ang), y0 + 4.2 + 0.9 * np.sin(ang), cz - 0.3 + 0.6 * v
+
+                    parts.append((1.2, arch, 8 + (i % 4), (3, 1)))
+    for i in range(6):  # drapes hanging from the galleries
+        x0 = -L + 3.0 + i * 4.6
+        side = -1. if i % 2 == 0 else 1.
+
+        def drape(u, v, x0=x0, side=side, i=i):
+            zc = side * (Wd - 2.3)
+            return (x0 + 2.2 * u, 5.4 - 3.0 * v + 0.1 * np.sin(6 * np.pi * u),
+                    zc + 0.35 * np.sin(10 * np.pi * u + i) * (0.3 + v))
+
+        parts.append((6., drape, 12 + i, (2, 2)))
+    total_w = sum(p[0] for p in parts)
+    tris, uvs, mids = [], [], []
+    budget = n_triangles - 1  # one pennant triangle closes odd totals
+    made = 0
+    for k, (w, f, m, tile) in enumerate(parts):
+        share = budget * w / total_w if k + 1 < len(parts) else budget - made
+        cells = max(1, int(share // 2))
+        nu = max(1, int(round(math.sqrt(cells * 2.0))))
+        nv = max(1, cells // nu)
+        t, uv = _grid(f, nu, nv, tile)
+        tris.append(t), uvs.append(uv), mids.append(np.full(len(t), mats[m % n_materials], dtype=np.int32))
+        made += len(t)
+    # filler: a strip of small pennants along the -z gallery rail until the exact count is reached
+    missing = n_triangles - made
+    if missing < 0:
+        raise ValueError("triangle budget too small for the atrium layout")
+    if missing:
+        i = np.arange(missing, dtype=np.float64)
+        x = -L + 0.5 + (2 * L - 1.0) * (i + 0.5) / missing
+        w_ = min(0.2, (2 * L - 1.0) / missing * 0.45)
+        p0 = np.stack([x - w_, np.full_like(x, 6.6), np.full_like(x, -Wd + 2.0)], 1)
+        p1 = np.stack([x + w_, np.full_like(x, 6.6), np.full_like(x, -Wd + 2.0)], 1)
+        p2 = np.stack([x, np.full_like(x, 6.2), np.full_like(x, -Wd + 2.05)], 1)
+        tris.append(np.stack([p0, p1, p2], 1))
+        uvs.append(np.tile(np.array([[0, 0], [1, 0], [.5, 1]], np.float32), (missing, 1, 1)))
+        mids.append(np.full(missing, mats[(n_materials - 1)], dtype=np.int32))
+    tri = np.concatenate(tris)
+    assert len(tri) == n_triangles, (len(tri), n_triangles)
+    first, n = b.triangles(tri, np.concatenate(mids), np.concatenate(uvs))
+    model = b.Bvh_range(first, n)  # like Obj::load -> Bvh::new(triangles) (src/loader/obj.rs:135)
+    light = b.Quad((-6., Hh + 1.5, -2.0), (12., 0, 0), (0, 0, 4.0), b.DiffuseLight(18., 17., 15.))
+    world = b.Bvh([model, light])
+    cam = CameraConfig(vertical_fov_degrees=55., aperture_size=0., look_from=(-13.0, 2.2, 0.6), look_at=(6.0, 4.5, -0.4),
+                       up=(0, 1, 0))
+    return b.finish(world, cam, (0.35, 0.5, 0.75), rc)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's test scenes (tests/scenes.rs)
+# ---------------------------------------------------------------------------------------------------------------
+def create_test_scene(render_config):
+    """tests/scenes.rs:17-122"""
+    b = SceneBuilder()
+    cam = CameraConfig(20., 0.1, (-5., 3., 6.), (.25, 1., 0.), (0., 1., 0.))
+    ground = b.Lambertian(b.ImageMap(load_image("textures/tex.jpg")))
+    glass = b.Dielectric(b.SolidColor(1., 1., 1.), None, 1.5)
+    light = b.DiffuseLight(10., 10., 10.)
+    red = b.Lambertian(b.SolidColor(1., 0., 0.))
+    world = [b.Quad((-5., 0., -15.), (20., 0., 0.), (0., 0., 20.), ground),
+             b.Sphere((-1., 1., 0.), 1., glass)]
+    world += b.new_box((0., 0., -.5), (1., 2., .5), red, RotationY(15.))
+    world.append(b.ConstantMedium(b.Bvh(b.new_box((0., 0., -.5), (1., 2., .5), red, Translation((0., 0., 1.)))), 0.1,
+                                  (1., 1., 1.)))
+    world += b.new_box((-1., 2., 0.), (-.5, 2.5, .5), red)
+    balls = []
+    for ii in range(0, 10, 2):
+        i = ii * 0.1
+        for jj in range(0, 10, 2):
+            j = jj * 0.1
+            for kk in range(0, 10, 2):
+                k = kk * 0.1
+                balls.append(b.Triangle((i, j + .05, k + .8), (i, j, k + .8), (i, j + .05, k), red))
+    world.append(b.Bvh(balls))
+    world.append(b.Triangle((1., .1, 2.), (3., .1, 2.), (2., .1, 1.), red))
+    world.append(b.Sphere((10., 5., 10.), 10., light))
+    world.append(b.Quad((0., 0., 0.), (2., 0., 0.), (0., 0., 2.), light, [RotationY(45.), Translation((-1., 10., -1.))]))
+    world.append(b.Triangle((-2., 1., -3.), (0., 1., -3.), (-1., 2., -3.), light))
+    return b.finish(b.Bvh(world), cam, (.2, .3, .5), render_config)
+
+
+def create_simple_test_scene(render_config, add_light):
+    """tests/scenes.rs:170-193"""
+    b = SceneBuilder()
+    cam = CameraConfig(20., 0.1, (0., 0., 4.), (0., 0., 0.), (0., 1., 0.))
+    yellow = b.Lambertian(b.SolidColor(1., 1., 0.))
+    light = b.DiffuseLight(10., 10., 10.)
+    world = []
+    if add_light:
+        world.append(b.Sphere((0., 100., 0.), 20., light))
+    world.append(b.Sphere((0., 0., 0.), .5, yellow))
+    return b.finish(b.Bvh(world), cam, (.2, .3, .5), render_config)
+
+
+def create_uv_scene(render_config):
+    """tests/scenes.rs:196-230"""
+    b = SceneBuilder()
+    cam = CameraConfig(20., 0., (0., 1., 5.), (0., 1., 0.), (0., 1., 0.))
+    light = b.DiffuseLight(10., 10., 10.)
+    checker = b.Lambertian(b.ImageMap(load_image("textures/checker.jpg")))
+    world = [b.Sphere((50., 50., 50.), 20., light),
+             b.Triangle((-1., 0., 0.), (1., 0., 0.), (0., 2., 0.), checker, None, uv=((-1., -1.), (2., -1.), (0., 2.)))]
+    return b.finish(b.Bvh(world), cam, (.2, .3, .5), render_config)
+
+
+def create_normal_mapping_scene(render_config, light_pos, normal_mapping_enabled):
+    """tests/scenes.rs:233-280"""
+    b = SceneBuilder()
+    cam = CameraConfig(40., 0., (.2, .2, 2.), (0., 0., 0.), (0., 1., 0.))
+    light = b.DiffuseLight(45., 45., 45.)
+    world = [b.Sphere(light_pos, 5., light)]
+    ntex = b.load_normal_texture(load_image("textures/normal.png")) if normal_mapping_enabled else None
+    mat = b.Lambertian(b.SolidColor(.8, .8, .8), ntex)
+    red = b.Lambertian(b.SolidColor(1., 0., 0.))
+    world += b.new_box((-.1, -.1, 0.), (.1, .1, 1.), red)
+    world.append(b.Quad((-1., -1., 0.), (2., 0., 0.), (0., 2., 0.), mat))
+    return b.finish(b.Bvh(world), cam, (0., 0., 0.), render_config)
+
+
+def create_normal_mapping_sphere_scene(render_config, light_pos):
+    """tests/scenes.rs:283-315"""
+    b = SceneBuilder()
+    cam = CameraConfig(40., 0., (.2, .2, 2.), (0., 0., 0.), (0., 1., 0.))
+    light = b.DiffuseLight(45., 45., 45.)
+    ntex = b.load_normal_texture(load_image("textures/earth_height.jpg"))
+    mat = b.Lambertian(b.SolidColor(.8, .8, .8), ntex)
+    world = [b.Sphere(light_pos, 5., light), b.Sphere((0., 0., 0.), .6, mat)]
+    return b.finish(b.Bvh(world), cam, (0., 0., 0.), render_config)
+
+
+def create_light_attenuation_scene(render_config, attenuation_half_length):
+    """tests/scenes.rs:412-449"""
+    b = SceneBuilder()
+    cam = CameraConfig(20., 0., (0., 1., 2.), (0., .2, 0.), (0., 1., 0.))
+    light = b.DiffuseLight(25., 25., 25., attenuation_half_length)
+    red = b.Lambertian(b.SolidColor(1., 0., 0.))
+    green = b.Lambertian(b.SolidColor(0., 1., 0.))
+    blue = b.Lambertian(b.SolidColor(0., 0., 1.))
+    glass = b.Dielectric(b.SolidColor(.8, .8, .8), None, 1.5)
+    world = [b.Sphere((0., .2, 0.), .03, light), b.Sphere((.25, .1, .25), .1, green), b.Sphere((.25, .1, -.5), .1, blue),
+             b.Sphere((-.1, .1, -.1), .1, glass), b.Quad((-1., 0., -1.), (2., 0., 0.), (0., 0., 2.), red)]
+    return b.finish(b.Bvh(world), cam, (0., 0., 0.), render_config)
+
+
+def create_quad_rotation_scene(render_config, rotation):
+    """tests/scenes.rs:452-479"""
+    b = SceneBuilder()
+    world = [b.Quad((-100., 0., -100.), (200., 0., 0.), (0., 0., 200.), b.Lambertian(b.SolidColor(0., 1., 0.)), rotation),
+             b.Sphere((100., 300., -500.), 50., b.DiffuseLight(15., 15., 15.))]
+    cam = CameraConfig(vertical_fov_degrees=35., look_from=(0., 200., -500.))
+    return b.finish(b.Bvh(world), cam, (0., 0., 0.), render_config)
+
+
+def create_blend_material_scene(render_config, blend_factor):
+    """tests/scenes.rs:482-513"""
+    b = SceneBuilder()
+    m = b.Blend(b.Lambertian(b.ImageMap(load_image("textures/checker.jpg"))), b.Lambertian(b.SolidColor(0., 1., 0.)),
+                blend_factor)
+    world = [b.Quad((-100., 0., -100.), (200., 0., 0.), (0., 0., 200.), m),
+             b.Sphere((0., 500., -200.), 50., b.DiffuseLight(15., 15., 15.))]
+    cam = CameraConfig(vertical_fov_degrees=35., look_from=(0., 400., -100.))
+    return b.finish(b.Bvh(world), cam, (0., 0., 0.), render_config)
+
+
+def new_bvh_test_scene(render_config, use_bvh, num_triangles):
+    """tests/scenes.rs:125-167 (bench-only scene in the reference)"""
+    b = SceneBuilder()
+    cam = CameraConfig(20., 0.1, (-.5, 0., 4.), (-.5, 0., 0.), (0., 1., 0.))
+    yellow = b.Lambertian(b.SolidColor(1., 1., 0.))
+    world = [b.Sphere((0., 4., 10.), 4., b.DiffuseLight(10., 10., 10.))]
+    tris = []
+    for x in range(num_triangles):
+        cx = x - num_triangles / 2.
+        tris.append(b.Triangle((cx, -.5, 0.), (cx + 1., -.5, 0.), (cx + .5, .5, 0.), yellow))
+    if use_bvh:
+        world.append(b.Bvh(tris))
+    else:
+        world += tris
+    return b.finish(b.Bvh(world), cam, (.2, .3, .5), render_config)
