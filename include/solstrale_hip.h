@@ -235,6 +235,12 @@ int sol_tonemap_rgb8(SolScene* scene, const void* image_dev, uint32_t num_sample
 
 int sol_stats(const SolScene* scene, SolStats* out);
 
+/* Function-level evaluation of the device code on n rows of host floats (in_stride / out_stride floats per row), for
+ * pinning the fp32 arithmetic contract bit for bit (tests/test_gpu_functions.py). fn: 0 arithmetic, 1 elementary
+ * functions, 2 RNG, 3 vector ops + Onb::new, 4 Sphere::hit, 5 Quad::hit, 6 Triangle::hit, 7 Aabb::hit, 8 sampling
+ * (row layouts: solstrale-rust_amd/csrc/sol_kernels.hip, sol_eval_kernel). No reference analogue. */
+int sol_eval(int device, uint32_t fn, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride);
+
 /* Sizes of the device records, for the algorithmic-bytes formula: node, sphere, quad, triangle
  * intersect records, shading record, material record (bytes). */
 int sol_record_sizes(uint32_t out[6]);

@@ -235,9 +235,29 @@ template <typename R> struct Scene {
     background = cv(d.background);
     cam_origin = cv(d.camera.origin); cam_llc = cv(d.camera.lower_left_corner); cam_h = cv(d.camera.horizontal);
     cam_v = cv(d.camera.vertical); cam_u = cv(d.camera.u); cam_vv = cv(d.camera.v); lens_radius = (R)d.camera.lens_radius;
+    // fp32 box contract: cast, then pad outward by S * 2^-20, S = largest finite |coordinate| of the world's
+    // box and the camera origin. The f64 instantiation keeps the reference's boxes untouched.
+    R pad = 0;
+    if (sizeof(R) == 4) {
+      float S = 0.0f;
+      auto take = [&](double v) { float a = std::fabs((float)v); if (std::isfinite(a) && a > S) S = a; };
+      const uint32_t k = SOL_REF_KIND(d.root), i = SOL_REF_INDEX(d.root);
+      const SolAabb* b = nullptr;
+      if (k == SOL_REF_NODE && i < d.n_nodes) b = &d.nodes[i].bbox;
+      else if (k == SOL_REF_SPHERE && i < d.n_spheres) b = &d.spheres[i].bbox;
+      else if (k == SOL_REF_QUAD && i < d.n_quads) b = &d.quads[i].bbox;
+      else if (k == SOL_REF_TRIANGLE && i < d.n_triangles) b = &d.triangles[i].bbox;
+      else if (k == SOL_REF_MEDIUM && i < d.n_mediums) b = &d.mediums[i].bbox;
+      if (b) for (int j = 0; j < 6; ++j) take(b->v[j]);
+      for (int j = 0; j < 3; ++j) take(d.camera.origin[j]);
+      pad = (R)(S * (1.0f / 1048576.0f));
+    }
     nodes.resize(d.n_nodes);
     for (uint32_t i = 0; i < d.n_nodes; ++i) {
-      for (int k = 0; k < 6; ++k) nodes[i].box[k] = (R)d.nodes[i].bbox.v[k];
+      for (int k = 0; k < 6; k += 2) {
+        nodes[i].box[k] = (R)d.nodes[i].bbox.v[k] - pad;
+        nodes[i].box[k + 1] = (R)d.nodes[i].bbox.v[k + 1] + pad;
+      }
       nodes[i].left = d.nodes[i].left; nodes[i].right = d.nodes[i].right;
     }
     spheres.resize(d.n_spheres);
@@ -765,6 +785,86 @@ void orc_f32_funcs(float r, float x, float y, float out[5]) {
   float c, s; sincos2pi(r, c, s);
   out[0] = c; out[1] = s; out[2] = acos_r(x); out[3] = atan2_r(y, x); out[4] = log_r(r);
 }
+// fp32 function table with the row layouts of the device's sol_eval (tests/test_gpu_functions.py compares bit for bit).
+int orc_eval_f32(uint32_t fn, const float* in, uint32_t n, uint32_t is, float* out, uint32_t os) {
+  typedef V3<float> F3;
+  auto u2f = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+  auto f2u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  SolSceneDesc empty{};
+  Scene<float> sc(empty);
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* x = in + (size_t)i * is;
+    float* y = out + (size_t)i * os;
+    Tracer<float> tr(sc);
+    const float inf = std::numeric_limits<float>::infinity();
+    (void)inf;
+    switch (fn) {
+      case 0: {
+        float a = x[0], b = x[1], c = x[2];
+        y[0] = a / b; y[1] = std::sqrt(std::fabs(a)); y[2] = 1.0f / a; y[3] = a * b + c; y[4] = std::fmax(a, b);
+        y[5] = std::fmin(a, b); y[6] = std::floor(a);
+        break;
+      }
+      case 1: {
+        float c, s; sincos2pi(x[0], c, s);
+        y[0] = c; y[1] = s; y[2] = acos_r(x[1]); y[3] = atan2_r(x[2], x[1]); y[4] = log_r(x[0]);
+        break;
+      }
+      case 2: {
+        Rng r; r.init(((uint64_t)f2u(x[1]) << 32) | f2u(x[0]), f2u(x[2]), f2u(x[3]));
+        y[0] = u2f(r.at(f2u(x[4]))); y[1] = u32_to_unit<float>(r.at(f2u(x[4])));
+        break;
+      }
+      case 3: {
+        F3 v{x[0], x[1], x[2]}, nn{x[3], x[4], x[5]};
+        F3 u = v.unit(), rf = v.reflect(nn), rr = v.refract(nn, x[6]);
+        Onb<float> o = Onb<float>::make(v);
+        const F3 r[6] = {u, rf, rr, o.tangent, o.bi_tangent, o.normal};
+        for (int k = 0; k < 6; ++k) { y[3 * k] = r[k].x; y[3 * k + 1] = r[k].y; y[3 * k + 2] = r[k].z; }
+        break;
+      }
+      case 4: {
+        Scene<float>::Sph S{{x[0], x[1], x[2]}, x[3], 0, 0};
+        Cand<float> c;
+        bool h = tr.hit_sphere(S, Ray<float>::make({x[4], x[5], x[6]}, {x[7], x[8], x[9]}), x[10], x[11], c);
+        y[0] = h ? 1.f : 0.f; y[1] = h ? c.t : 0.f;
+        break;
+      }
+      case 5: {
+        Scene<float>::Qd Q{{x[4], x[5], x[6]}, {x[10], x[11], x[12]}, {x[13], x[14], x[15]}, {x[0], x[1], x[2]}, {x[7], x[8], x[9]}, x[3], 0, 0, 0};
+        Cand<float> c;
+        bool h = tr.hit_quad(Q, Ray<float>::make({x[16], x[17], x[18]}, {x[19], x[20], x[21]}), x[22], x[23], c);
+        y[0] = h ? 1.f : 0.f; y[1] = h ? c.t : 0.f; y[2] = h ? c.uv.u : 0.f; y[3] = h ? c.uv.v : 0.f;
+        break;
+      }
+      case 6: {
+        // uv0=(0,0), uv1=(1,0), uv2=(0,1) make the interpolated Uv equal the barycentrics (u, v)
+        Scene<float>::Tri T{{x[0], x[1], x[2]}, {x[3], x[4], x[5]}, {x[6], x[7], x[8]}, {0, 0, 1}, {1, 0, 0}, {0, 1, 0}, 0,
+                            {0.f, 0.f}, {1.f, 0.f}, {0.f, 1.f}, 0, 0};
+        Cand<float> c;
+        bool h = tr.hit_triangle(T, Ray<float>::make({x[9], x[10], x[11]}, {x[12], x[13], x[14]}), x[15], x[16], c);
+        y[0] = h ? 1.f : 0.f; y[1] = h ? c.t : 0.f; y[2] = h ? c.uv.u : 0.f; y[3] = h ? c.uv.v : 0.f;
+        break;
+      }
+      case 7: {
+        Ray<float> r = Ray<float>::make({x[6], x[7], x[8]}, {x[9], x[10], x[11]});
+        y[0] = aabb_hit<float>(x, r) ? 1.f : 0.f;
+        y[1] = 0.f;  // the reference's Aabb::hit returns only the predicate
+        break;
+      }
+      case 8: {
+        tr.rng.init(((uint64_t)f2u(x[1]) << 32) | f2u(x[0]), f2u(x[2]), f2u(x[3]));
+        F3 c = tr.random_cosine_direction();
+        F3 s = tr.random_in_unit_sphere();
+        y[0] = c.x; y[1] = c.y; y[2] = c.z; y[3] = s.x; y[4] = s.y; y[5] = s.z; y[6] = u2f(tr.rng.ctr);
+        break;
+      }
+      default: return -1;
+    }
+  }
+  return 0;
+}
+
 // Closest hit of one ray in reference order (for traversal parity tests): returns 1 and fills t / prim ref.
 int orc_closest_hit(const SolSceneDesc* d, int real_kind, const double o[3], const double dir[3], double* t_out, uint32_t* mat_out) {
   if (real_kind == ORC_F32) {

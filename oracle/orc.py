@@ -64,6 +64,7 @@ def load():
     sig("orc_to_rgb_color", None, [_D, C.c_uint32, U8])
     sig("orc_rng_bits", C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32])
     sig("orc_f32_funcs", None, [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)])
+    sig("orc_eval_f32", C.c_int, [C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32])
     sig("orc_closest_hit", C.c_int, [C.POINTER(_abi.SolSceneDesc), C.c_int, _D, _D, _D, C.POINTER(C.c_uint32)])
     _lib = lib
     return lib
@@ -82,6 +83,17 @@ def render(scene, first_sample, n_samples, seed, real=ORC_F32, rect=None, thread
     if rc != 0:
         raise RuntimeError({-1: "orc_render: bad input", -2: "Scene should have at least one light"}.get(rc, str(rc)))
     return out, st.as_dict()
+
+
+def eval_f32(fn, rows, out_cols):
+    """fp32 function table (same row layouts as the device's sol_eval)."""
+    lib = load()
+    a = np.ascontiguousarray(rows, dtype=np.float32)
+    out = np.zeros((a.shape[0], out_cols), dtype=np.float32)
+    rc = lib.orc_eval_f32(fn, a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data, out_cols)
+    if rc != 0:
+        raise RuntimeError("orc_eval_f32 failed")
+    return out
 
 
 def v3(a):

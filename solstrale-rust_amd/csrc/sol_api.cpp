@@ -40,10 +40,32 @@ struct Box {
 };
 const float F_INF = std::numeric_limits<float>::infinity();
 Box empty_box() { return Box{{F_INF, -F_INF, F_INF, -F_INF, F_INF, -F_INF}}; }
+// fp32 box contract (DESIGN.md "fp32 arithmetic contract"): cast, then pad outward by g_box_pad = S * 2^-20 where S is
+// the largest finite |coordinate| of the world's box and the camera origin. PAD_DELTA (1e-4, src/geo/mod.rs:11) is sized
+// for f64; in fp32 a flat box seen from a distant origin collapses ((554.99994+800) == (555.00006+800) == 1355.0f) and
+// the slab test t_min < t_max fails. With the pad every fp32 slab test is conservative.
+thread_local float g_box_pad = 0.0f;
 Box cast_box(const SolAabb& b) {
   Box r;
-  for (int i = 0; i < 6; ++i) r.v[i] = (float)b.v[i];
+  for (int i = 0; i < 6; i += 2) {
+    r.v[i] = (float)b.v[i] - g_box_pad;
+    r.v[i + 1] = (float)b.v[i + 1] + g_box_pad;
+  }
   return r;
+}
+float box_pad_for(const SolSceneDesc& d) {
+  float S = 0.0f;
+  auto take = [&](double v) { float a = std::fabs((float)v); if (std::isfinite(a) && a > S) S = a; };
+  const uint32_t k = SOL_REF_KIND(d.root), i = SOL_REF_INDEX(d.root);
+  const SolAabb* b = nullptr;
+  if (k == SOL_REF_NODE && i < d.n_nodes) b = &d.nodes[i].bbox;
+  else if (k == SOL_REF_SPHERE && i < d.n_spheres) b = &d.spheres[i].bbox;
+  else if (k == SOL_REF_QUAD && i < d.n_quads) b = &d.quads[i].bbox;
+  else if (k == SOL_REF_TRIANGLE && i < d.n_triangles) b = &d.triangles[i].bbox;
+  else if (k == SOL_REF_MEDIUM && i < d.n_mediums) b = &d.mediums[i].bbox;
+  if (b) for (int j = 0; j < 6; ++j) take(b->v[j]);
+  for (int j = 0; j < 3; ++j) take(d.camera.origin[j]);
+  return S * (1.0f / 1048576.0f);
 }
 
 // Converts the reference-shaped tree (own box per node) into device nodes (child boxes in the parent).
@@ -109,7 +131,9 @@ struct TreeBuilder {
     DNode& dn = nodes[di];
     dn.lxmin = lb.v[0]; dn.lxmax = lb.v[1]; dn.lymin = lb.v[2]; dn.lymax = lb.v[3]; dn.lzmin = lb.v[4]; dn.lzmax = lb.v[5];
     dn.rxmin = rb.v[0]; dn.rxmax = rb.v[1]; dn.rymin = rb.v[2]; dn.rymax = rb.v[3]; dn.rzmin = rb.v[4]; dn.rzmax = rb.v[5];
-    dn.left = lr; dn.right = rr; dn.pad0 = dn.pad1 = 0;
+    dn.left = lr; dn.right = rr; dn.pad1 = 0;
+    // flags: bit0 / bit1 = the left / right box is a direct leaf's own box, which the reference never tests (sol_trace.h)
+    dn.pad0 = ((lk != SOL_REF_NONE && lk != SOL_REF_NODE) ? 1u : 0u) | ((rk != SOL_REF_NONE && rk != SOL_REF_NODE) ? 2u : 0u);
     out_ref = SOL_MAKE_REF(SOL_REF_NODE, di);
     out_box = cast_box(n.bbox);
     return true;
@@ -300,6 +324,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   }
 
   // ---- tree ----
+  g_box_pad = box_pad_for(*d);
   TreeBuilder tb(*d);
   uint32_t root_ref;
   Box root_box;
@@ -524,6 +549,26 @@ int sol_tonemap_rgb8(SolScene* s, const void* image, uint32_t spp, uint8_t* out)
   HIP_TRY(sol_launch_tonemap((const float*)image, s->rgb8, n, spp, s->stream));
   HIP_TRY(hipMemcpyAsync(out, s->rgb8, n, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return SOL_OK;
+}
+
+int sol_eval(int device, uint32_t fn, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride) {
+  if (!in || !out || !in_stride || !out_stride) return fail(SOL_EINVAL, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SOL_EDEVICE, "no HIP device available");
+  HIP_TRY(hipSetDevice(device));
+  float *din = nullptr, *dout = nullptr;
+  const size_t ib = (size_t)n * in_stride * sizeof(float), ob = (size_t)n * out_stride * sizeof(float);
+  HIP_TRY(hipMalloc((void**)&din, std::max<size_t>(ib, 64)));
+  if (hipMalloc((void**)&dout, std::max<size_t>(ob, 64)) != hipSuccess) { hipFree(din); return fail(SOL_ENOMEM, "hipMalloc failed"); }
+  hipError_t e = hipMemcpy(din, in, ib, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(dout, 0, std::max<size_t>(ob, 64));
+  if (e == hipSuccess) e = sol_launch_eval(fn, din, n, in_stride, dout, out_stride, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost);
+  hipFree(din);
+  hipFree(dout);
+  if (e != hipSuccess) return fail(SOL_EDEVICE, "sol_eval: %s", hipGetErrorString(e));
   return SOL_OK;
 }
 

@@ -291,3 +291,91 @@ hipError_t sol_launch_tonemap(const float* image, uint8_t* rgb, uint32_t n, uint
   hipLaunchKernelGGL(sol_tonemap_kernel, dim3(grid), dim3(256), 0, stream, image, rgb, n, spp);
   return hipGetLastError();
 }
+
+// ---- function-level evaluation (sol_eval): the device functions of sol_math.h / sol_trace.h on arrays of inputs, so that
+// tests can pin the fp32 arithmetic contract bit for bit against the CPU restatement -------------------------------------
+__global__ void __launch_bounds__(256) sol_eval_kernel(uint32_t fn, const float* __restrict__ in, uint32_t n, uint32_t is,
+                                                       float* __restrict__ out, uint32_t os) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* x = in + (size_t)i * is;
+  float* y = out + (size_t)i * os;
+  switch (fn) {
+    case 0: {  // arithmetic: a/b, sqrt|a|, 1/a, a*b+c (unfused), fmax, fmin, floor
+      float a = x[0], b = x[1], c = x[2];
+      y[0] = a / b; y[1] = sol_sqrt(fabsf(a)); y[2] = 1.0f / a; y[3] = a * b + c; y[4] = fmaxf(a, b); y[5] = fminf(a, b);
+      y[6] = floorf(a);
+      break;
+    }
+    case 1: {  // elementary functions: r in [0,1), x in [-1,1], y
+      float c, s;
+      sincos2pi(x[0], c, s);
+      y[0] = c; y[1] = s; y[2] = acos_r(x[1]); y[3] = atan2_r(x[2], x[1]); y[4] = log_r(x[0]);
+      break;
+    }
+    case 2: {  // rng: seed_lo, seed_hi, pixel, sample, counter (bit patterns)
+      Rng r;
+      rng_init(r, __float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+      y[0] = __uint_as_float(rng_bits(r, __float_as_uint(x[4])));
+      y[1] = u32_to_unit(rng_bits(r, __float_as_uint(x[4])));
+      break;
+    }
+    case 3: {  // vectors: v(3), n(3), ior -> unit(v), reflect(v,n), refract(v,n,ior), onb_new(v)
+      f3 v = mk3(x[0], x[1], x[2]), nn = mk3(x[3], x[4], x[5]);
+      f3 u = unit3(v), rf = reflect3(v, nn), rr = refract3(v, nn, x[6]);
+      Onb o = onb_new(v);
+      y[0] = u.x; y[1] = u.y; y[2] = u.z; y[3] = rf.x; y[4] = rf.y; y[5] = rf.z; y[6] = rr.x; y[7] = rr.y; y[8] = rr.z;
+      y[9] = o.tangent.x; y[10] = o.tangent.y; y[11] = o.tangent.z; y[12] = o.bi_tangent.x; y[13] = o.bi_tangent.y;
+      y[14] = o.bi_tangent.z; y[15] = o.normal.x; y[16] = o.normal.y; y[17] = o.normal.z;
+      break;
+    }
+    case 4: {  // sphere: center(3), radius, o(3), d(3), tmin, tmax -> hit, t
+      DSphere S; S.cx = x[0]; S.cy = x[1]; S.cz = x[2]; S.radius = x[3]; S.dfs = 0; S.mat = 0; S.pad0 = S.pad1 = 0;
+      float t = 0.f;
+      bool h = sphere_test(S, mk3(x[4], x[5], x[6]), mk3(x[7], x[8], x[9]), x[10], x[11], t);
+      y[0] = h ? 1.f : 0.f; y[1] = h ? t : 0.f;
+      break;
+    }
+    case 5: {  // quad: n(3), d, q(3), w(3), u(3), v(3), o(3), dir(3), tmin, tmax -> hit, t, u, v
+      DQuad Q; Q.nx = x[0]; Q.ny = x[1]; Q.nz = x[2]; Q.d = x[3]; Q.qx = x[4]; Q.qy = x[5]; Q.qz = x[6];
+      Q.wx = x[7]; Q.wy = x[8]; Q.wz = x[9]; Q.ux = x[10]; Q.uy = x[11]; Q.uz = x[12]; Q.vx = x[13]; Q.vy = x[14]; Q.vz = x[15];
+      Q.dfs = 0; Q.mat = 0; Q.area = 0; Q.pad = 0;
+      float t = 0.f, u = 0.f, v = 0.f;
+      bool h = quad_test(Q, mk3(x[16], x[17], x[18]), mk3(x[19], x[20], x[21]), x[22], x[23], t, u, v);
+      y[0] = h ? 1.f : 0.f; y[1] = h ? t : 0.f; y[2] = h ? u : 0.f; y[3] = h ? v : 0.f;
+      break;
+    }
+    case 6: {  // triangle: v0(3), e1(3), e2(3), o(3), dir(3), tmin, tmax -> hit, t, u, v
+      DTri T; T.v0x = x[0]; T.v0y = x[1]; T.v0z = x[2]; T.e1x = x[3]; T.e1y = x[4]; T.e1z = x[5]; T.e2x = x[6]; T.e2y = x[7];
+      T.e2z = x[8]; T.dfs = 0; T.mat = 0; T.pad = 0;
+      float t = 0.f, u = 0.f, v = 0.f;
+      bool h = tri_test(T, mk3(x[9], x[10], x[11]), mk3(x[12], x[13], x[14]), x[15], x[16], t, u, v);
+      y[0] = h ? 1.f : 0.f; y[1] = h ? t : 0.f; y[2] = h ? u : 0.f; y[3] = h ? v : 0.f;
+      break;
+    }
+    case 7: {  // slab: box(6: xmin,xmax,ymin,ymax,zmin,zmax), o(3), dir(3) -> hit, t_entry
+      f3 d = mk3(x[9], x[10], x[11]);
+      f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+      float te = 0.f;
+      bool h = slab(x[0], x[1], x[2], x[3], x[4], x[5], mk3(x[6], x[7], x[8]), inv, __builtin_signbitf(inv.x),
+                    __builtin_signbitf(inv.y), __builtin_signbitf(inv.z), te);
+      y[0] = h ? 1.f : 0.f; y[1] = te;
+      break;
+    }
+    case 8: {  // sampling: seed bits, pixel, sample -> random_cosine_direction (3), random_in_unit_sphere (3), counter after
+      Rng r;
+      rng_init(r, __float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+      f3 c = random_cosine_direction(r);
+      f3 s = random_in_unit_sphere(r);
+      y[0] = c.x; y[1] = c.y; y[2] = c.z; y[3] = s.x; y[4] = s.y; y[5] = s.z; y[6] = __uint_as_float(r.ctr);
+      break;
+    }
+    default: break;
+  }
+}
+
+hipError_t sol_launch_eval(uint32_t fn, const float* in, uint32_t n, uint32_t is, float* out, uint32_t os, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(sol_eval_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, fn, in, n, is, out, os);
+  return hipGetLastError();
+}

@@ -133,7 +133,7 @@ DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Co
     if (COUNT) cnt.sphere_tests++;
     float t;
     if (!sphere_test(Sp, origin, dir, RAY_MIN_F, inf, t)) return 0.0f;
-    float cos_theta_max = __fsqrt_rn(1.0f - Sp.radius * Sp.radius / len2(mk3(Sp.cx, Sp.cy, Sp.cz) - origin));
+    float cos_theta_max = sol_sqrt(1.0f - Sp.radius * Sp.radius / len2(mk3(Sp.cx, Sp.cy, Sp.cz) - origin));
     float solid_angle = 2.0f * SOL_PI * (1.0f - cos_theta_max);
     return 1.0f / solid_angle;
   }
@@ -157,10 +157,10 @@ DEV f3 light_random_direction(const DevScene& S, uint32_t ref, f3 origin, Rng& r
   Onb uvw = onb_new(direction);
   float ds = len2(direction);
   float r1 = rnd(rng), r2 = rnd(rng);
-  float z = 1.0f + r2 * (__fsqrt_rn(1.0f - Sp.radius * Sp.radius / ds) - 1.0f);
+  float z = 1.0f + r2 * (sol_sqrt(1.0f - Sp.radius * Sp.radius / ds) - 1.0f);
   float c, s;
   sincos2pi(r1, c, s);
-  float zz = __fsqrt_rn(1.0f - z * z);
+  float zz = sol_sqrt(1.0f - z * z);
   return onb_local(uvw, mk3(c * zz, s * zz, z));
 }
 template <bool COUNT>
@@ -185,10 +185,10 @@ DEV f3 random_in_unit_sphere(Rng& rng) {  // vec3.rs:380-392 (bound never reache
 }
 DEV f3 random_cosine_direction(Rng& rng) {  // vec3.rs:417-428
   float r1 = rnd(rng), r2 = rnd(rng);
-  float r2_sqrt = __fsqrt_rn(r2);
+  float r2_sqrt = sol_sqrt(r2);
   float c, s;
   sincos2pi(r1, c, s);
-  return mk3(c * r2_sqrt, s * r2_sqrt, __fsqrt_rn(1.0f - r2));
+  return mk3(c * r2_sqrt, s * r2_sqrt, sol_sqrt(1.0f - r2));
 }
 
 // RayScatter (material/mod.rs:60-93)
@@ -236,7 +236,7 @@ DEV void scatter(const DevScene& S, f3 ray_dir, const Surface& sf, Rng& rng, Sca
     float ratio = sf.front ? 1.0f / m.param : m.param;
     f3 ud = unit3(ray_dir);
     float cos_theta = fminf(dot3(neg3(ud), sf.normal), 1.0f);
-    float sin_theta = __fsqrt_rn(1.0f - cos_theta * cos_theta);
+    float sin_theta = sol_sqrt(1.0f - cos_theta * cos_theta);
     bool refl = ratio * sin_theta > 1.0f;
     if (!refl) {  // reflectance (mod.rs:312-316); the draw happens only when refraction is possible
       float r0 = (1.0f - ratio) / (1.0f + ratio);

@@ -95,7 +95,7 @@ DEV bool sphere_test(const DSphere& S, f3 o, f3 d, float tmin, float tmax, float
   float c = len2(oc) - S.radius * S.radius;
   float disc = half_b * half_b - a * c;
   if (disc < 0.0f) return false;
-  float sqrt_d = __fsqrt_rn(disc);
+  float sqrt_d = sol_sqrt(disc);
   float root = (-half_b - sqrt_d) / a;
   if (!(tmin <= root && root <= tmax)) {
     root = (-half_b + sqrt_d) / a;
@@ -179,9 +179,20 @@ DEV void closest_hit(const DevScene& S, f3 o, f3 d, f3 inv, float tmin, float tm
       const float4 a = np[0], b = np[1], c = np[2];
       const uint4 r = *reinterpret_cast<const uint4*>(np + 3);
       if (COUNT) cnt.node_visits++;
+      // Culling: a box whose entry parameter lies beyond the best hit cannot hold a better one. The slab test clamps the
+      // entry to 0 (origin inside the box), and a search over (-inf, inf) (constant-medium boundary) accepts hits at
+      // negative t, so boxes entered at 0 are never culled.
+      const float cull_t = fmaxf(h.t, 0.0f);
       float tl, tr;
-      bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tl) && tl <= h.t;
-      bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tr) && tr <= h.t;
+      bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tl) && tl <= cull_t;
+      bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tr) && tr <= cull_t;
+      if (tmin < 0.0f) {
+        // r.z bit0/bit1: that child's box is the primitive's own box, which the reference does not test (a two-leaf
+        // `Bvh` tests only its union box, bvh.rs:91-96). For t >= 0 the extra test is a sound cull; a primitive hit at
+        // negative t lies outside the forward slab, so here the child is taken whenever the node was reached.
+        if (r.z & 1u) { hl = true; tl = 0.0f; }
+        if (r.z & 2u) { hr = true; tr = 0.0f; }
+      }
       if (hl && hr) {
         const bool lfirst = tl <= tr;
         stack_push(st, sp, lfirst ? r.y : r.x);

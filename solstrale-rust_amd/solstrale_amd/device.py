@@ -24,6 +24,17 @@ def record_sizes():
     return dict(zip(("node", "sphere", "quad", "triangle", "triangle_shade", "material"), [int(x) for x in out]))
 
 
+def eval_functions(fn, rows, out_cols, device=0):
+    """sol_eval: device functions on rows of fp32 inputs (function-level parity tests)."""
+    lib = _abi.load_hip()
+    a = np.ascontiguousarray(rows, dtype=np.float32)
+    out = np.zeros((a.shape[0], out_cols), dtype=np.float32)
+    rc = lib.sol_eval(device, fn, a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data, out_cols)
+    if rc != 0:
+        raise DeviceError(rc, lib.sol_last_error().decode())
+    return out
+
+
 class DeviceScene:
     """sol_scene_create .. sol_scene_destroy"""
 
