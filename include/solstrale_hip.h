@@ -235,6 +235,12 @@ int sol_tonemap_rgb8(SolScene* scene, const void* image_dev, uint32_t num_sample
 
 int sol_stats(const SolScene* scene, SolStats* out);
 
+/* Measurement: with timing enabled every sol_render brackets its render kernel with HIP events on the stream it is
+ * launched on; sol_last_kernel_ms blocks on the last one and returns its duration (and the grid it was launched with).
+ * No reference analogue (the reference reports only passes/s, src/renderer/mod.rs:367-373). */
+int sol_kernel_timing(SolScene* scene, int enable);
+int sol_last_kernel_ms(SolScene* scene, float* ms, uint32_t* grid_blocks);
+
 /* Function-level evaluation of the device code on n rows of host floats (in_stride / out_stride floats per row), for
  * pinning the fp32 arithmetic contract bit for bit (tests/test_gpu_functions.py). fn: 0 arithmetic, 1 elementary
  * functions, 2 RNG, 3 vector ops + Onb::new, 4 Sphere::hit, 5 Quad::hit, 6 Triangle::hit, 7 Aabb::hit, 8 sampling

@@ -172,6 +172,9 @@ struct SolScene {
   int rank = 0, world = 1;
   uint32_t blocks_x = 0, blocks_y = 0, n_local_blocks = 0;
   int n_cu = 0;
+  bool timing = false;  // sol_kernel_timing: HIP events around the render kernel on its own stream
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  uint32_t timed_launches = 0, last_grid = 0;
 };
 
 static int set_partition(SolScene* s, int rank, int world) {
@@ -216,6 +219,8 @@ void sol_scene_destroy(SolScene* s) {
                   s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  if (s->ev_start) hipEventDestroy(s->ev_start);
+  if (s->ev_stop) hipEventDestroy(s->ev_stop);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
 }
@@ -500,7 +505,10 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
   }
   HIP_TRY(hipMemsetAsync(s->work, 0, sizeof(uint32_t), s->stream));
   if (count) HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(DevCounters), s->stream));
+  if (s->timing) HIP_TRY(hipEventRecord(s->ev_start, s->stream));
   HIP_TRY(sol_launch_render(s->S, P, s->acc, s->partial, s->work, s->spill, s->counters, grid, count, s->has_medium, s->stream));
+  if (s->timing) { HIP_TRY(hipEventRecord(s->ev_stop, s->stream)); s->timed_launches++; }
+  s->last_grid = grid;
   if (P.n_chunks > 1) HIP_TRY(sol_launch_resolve(s->acc, s->partial, (uint32_t)slots3, P.n_chunks, s->stream));
   if (count) {
     DevCounters c;
@@ -569,6 +577,28 @@ int sol_eval(int device, uint32_t fn, const float* in, uint32_t n, uint32_t in_s
   hipFree(din);
   hipFree(dout);
   if (e != hipSuccess) return fail(SOL_EDEVICE, "sol_eval: %s", hipGetErrorString(e));
+  return SOL_OK;
+}
+
+int sol_kernel_timing(SolScene* s, int enable) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  if (enable && !s->ev_start) {
+    HIP_TRY(hipEventCreate(&s->ev_start));
+    HIP_TRY(hipEventCreate(&s->ev_stop));
+  }
+  s->timing = enable != 0;
+  s->timed_launches = 0;
+  return SOL_OK;
+}
+
+int sol_last_kernel_ms(SolScene* s, float* ms, uint32_t* grid_blocks) {
+  if (!s || !ms) return fail(SOL_EINVAL, "null argument");
+  if (!s->timing || s->timed_launches == 0) return fail(SOL_EINVAL, "no timed render launch (call sol_kernel_timing first)");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->ev_stop));
+  HIP_TRY(hipEventElapsedTime(ms, s->ev_start, s->ev_stop));
+  if (grid_blocks) *grid_blocks = s->last_grid;
   return SOL_OK;
 }
 

@@ -202,9 +202,9 @@ sol_render_kernel(const DevScene S, const RenderParams P, float* __restrict__ ac
 __global__ void __launch_bounds__(256) sol_resolve_kernel(float* __restrict__ acc, const float* __restrict__ partial,
                                                           uint32_t n_floats, uint32_t n_chunks) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_floats; i += gridDim.x * blockDim.x) {
-    float s = 0.0f;
+    float s = acc[i];  // ((acc + c0) + c1) + ...: the same association whether the chunks come from one call or several
     for (uint32_t k = 0; k < n_chunks; ++k) s += partial[(size_t)k * n_floats + i];
-    acc[i] += s;
+    acc[i] = s;
   }
 }
 

@@ -143,6 +143,8 @@ def load_hip():
     _sig(lib, "sol_stats", C.c_int, [P, C.POINTER(SolStats)])
     _sig(lib, "sol_record_sizes", C.c_int, [C.POINTER(C.c_uint32)])
     _sig(lib, "sol_last_error", C.c_char_p, [])
+    _sig(lib, "sol_kernel_timing", C.c_int, [P, C.c_int])
+    _sig(lib, "sol_last_kernel_ms", C.c_int, [P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)])
     _sig(lib, "sol_eval", C.c_int, [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32])
     _libs["hip"] = lib
     return lib
@@ -151,7 +153,7 @@ def load_hip():
 HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol_scene_set_partition",
                "sol_accum_floats", "sol_accum_ptr", "sol_scene_bind_accum", "sol_scene_set_stream", "sol_clear",
                "sol_render", "sol_render_counted", "sol_sync", "sol_read", "sol_unpermute", "sol_tonemap_rgb8",
-               "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval"]
+               "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms"]
 
 
 def load_host():

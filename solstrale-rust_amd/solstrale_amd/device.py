@@ -108,6 +108,14 @@ class DeviceScene:
                                             out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
+    def kernel_timing(self, enable=True):
+        self._chk(self.lib.sol_kernel_timing(self.h, 1 if enable else 0))
+
+    def last_kernel_ms(self):
+        ms, grid = C.c_float(), C.c_uint32()
+        self._chk(self.lib.sol_last_kernel_ms(self.h, C.byref(ms), C.byref(grid)))
+        return float(ms.value), int(grid.value)
+
     def stats(self):
         st = _abi.SolStats()
         self._chk(self.lib.sol_stats(self.h, C.byref(st)))

@@ -1,0 +1,77 @@
+"""The C-ABI libraries load, export every symbol include/*.h declares, the Python struct mirror has the C layout, and the
+product has no CPU fallback (without a GPU every compute entry point fails loudly with SOL_EDEVICE)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from solstrale_amd import DeviceError, DeviceScene, RenderConfig, _abi, device_count, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    lib = _abi.load_hip()
+    names = _declared("solstrale_hip.h", "sol_")
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"libsolstrale_hip.so does not export {n}"
+    assert sorted(_abi.HIP_SYMBOLS) == names
+
+
+def test_host_library_exports_every_declared_symbol():
+    lib = _abi.load_host()
+    names = [n for n in _declared("solstrale_host.h", "solh_") if not n.endswith("_fn")]
+    for n in names:
+        assert hasattr(lib, n), f"libsolstrale_host.so does not export {n}"
+    assert sorted(_abi.HOST_SYMBOLS) == names
+
+
+def test_struct_layouts_match_the_c_side():
+    lib = _abi.load_host()
+    sizes = (C.c_uint32 * 11)()
+    lib.solh_abi_sizes(sizes)
+    assert [int(x) for x in sizes] == [C.sizeof(s) for s in _abi.ABI_STRUCTS]
+
+
+def test_device_record_sizes():
+    from solstrale_amd import record_sizes
+    assert record_sizes() == {"node": 64, "sphere": 32, "quad": 80, "triangle": 48, "triangle_shade": 64, "material": 32}
+
+
+def test_hip_library_is_a_gfx950_code_object():
+    data = open(_abi.HIP_LIB, "rb").read()
+    assert b"gfx950" in data and b"sol_render_kernel" in data
+
+
+@pytest.mark.skipif(device_count() > 0, reason="only meaningful without a GPU")
+def test_no_cpu_fallback_without_a_gpu():
+    sc = scenes.cornell_box(RenderConfig(16, 16, 1))
+    with pytest.raises(DeviceError) as e:
+        DeviceScene(sc)
+    assert e.value.code == _abi.SOL_EDEVICE
+
+
+def test_scene_validation_happens_before_the_device():
+    # Renderer::new's light check is part of sol_scene_create (SOL_ENOLIGHT) and does not need a GPU
+    sc = scenes.create_simple_test_scene(RenderConfig(20, 10, 1), add_light=False)
+    with pytest.raises(DeviceError) as e:
+        DeviceScene(sc)
+    assert e.value.code == _abi.SOL_ENOLIGHT and e.value.msg == "Scene should have at least one light"
+    sc = scenes.cornell_box(RenderConfig(16, 16, 1))
+    sc.desc.abi_version = 99
+    with pytest.raises(DeviceError) as e:
+        DeviceScene(sc)
+    assert e.value.code == _abi.SOL_EINVAL
+    sc.desc.abi_version = _abi.SOL_ABI_VERSION
+    sc.desc.root = (1 << 28) | 4000  # node index out of range
+    with pytest.raises(DeviceError) as e:
+        DeviceScene(sc)
+    assert e.value.code == _abi.SOL_EINVAL

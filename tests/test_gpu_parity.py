@@ -1,0 +1,316 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the fp32 oracle on the same seeded inputs, against the
+reference's golden images, and - at BASELINE.json's full sizes - through size-independent properties.
+
+Tolerance (north star): per-channel relative error <= 1e-5 at a fixed seed; the only arithmetic difference between the two
+sides is the re-association of the throughput product (DESIGN.md "Flattened recursion"), a few ulp.
+"""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import image_metric as im
+import orc
+import parity_util as pu
+from ref_cases import CASES
+from solstrale_amd import (AlbedoShader, DeviceError, DeviceScene, NormalShader, PathTracingShader, RenderConfig, SceneBuilder,
+                           SimpleShader, CameraConfig, _abi, scenes)
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "expected")
+
+
+def gpu_render(scene, spp, first=0, seed=pu.SEED):
+    with DeviceScene(scene) as ds:
+        ds.render(first, spp, seed)
+        return ds.read()
+
+
+def assert_parity(scene, spp, rect=None, max_bad=0, first=0):
+    img = gpu_render(scene, spp, first)
+    ref, _ = orc.render(scene, first, spp, pu.SEED, real=orc.ORC_F32, rect=rect)
+    res = pu.compare(img, ref, spp, rect)
+    assert np.isfinite(img).all()
+    assert res["bad_pixels"] <= max_bad, res
+    assert res["max_rel"] <= pu.REL_TOL, res
+    assert res["rmse_mean_good"] < 1e-5, res
+    return res
+
+
+# ---- BASELINE configs ------------------------------------------------------------------------------------------
+def test_c1_cornell_full():
+    """configs[0]: Cornell box 400x400, 50 spp, every pixel."""
+    res = assert_parity(scenes.cornell_box(RenderConfig(400, 400, 50)), 50)
+    assert res["rmse_mean"] < 1e-5  # north star: per-channel RMSE < 1e-5 vs CPU at fixed seed
+
+
+def test_c2_cornell_spheres_crop():
+    """configs[1] at full resolution and scene size, 128x128 crop x 16 spp against the oracle."""
+    assert_parity(scenes.cornell_spheres(RenderConfig(1920, 1080, 16)), 16, rect=(900, 500, 1028, 628))
+
+
+def test_c3_sponza_class_crop():
+    """configs[2]: 262 267 triangles, 1080p, 128x128 crop x 16 spp."""
+    sc = scenes.sponza_like(RenderConfig(1920, 1080, 16))
+    assert sc.desc.n_triangles == scenes.SPONZA_TRIANGLES
+    assert_parity(sc, 16, rect=(900, 500, 1028, 628))
+    assert_parity(sc, 4, rect=(0, 952, 128, 1080))  # a corner: floor + walls, other BVH regions
+
+
+def test_c5_shape_dielectric_metal_crop():
+    """configs[4] shape: triangle mesh + dielectric and metal spheres; crop against the oracle."""
+    assert_parity(_atrium_with_bsdfs(RenderConfig(640, 360, 16)), 16, rect=(256, 116, 384, 244))
+
+
+def _atrium_with_bsdfs(rc):
+    b = SceneBuilder()
+    mats = [b.Lambertian(b.SolidColor(.7, .6, .5)), b.Lambertian(b.SolidColor(.3, .5, .7))]
+    tri, uv = scenes._grid(lambda u, v: (-8 + 16 * u, 0 * u, -8 + 16 * v), 40, 40)
+    first, n = b.triangles(tri, np.full(len(tri), mats[0], np.int32), uv)
+    tri2, uv2 = scenes._grid(lambda u, v: (-8 + 16 * u, 6 * v, -8 + 0 * u + 0.3 * np.sin(9 * u)), 60, 20)
+    f2, n2 = b.triangles(tri2, np.full(len(tri2), mats[1], np.int32), uv2)
+    model = b.Bvh_range(first, n + n2)
+    glass = b.Sphere((-1.5, 1.2, 0.), 1.2, b.Dielectric(b.SolidColor(1., 1., 1.), None, 1.5))
+    metal = b.Sphere((1.8, 1.0, -1.), 1.0, b.Metal(b.SolidColor(.9, .8, .6), None, 0.1))
+    light = b.Quad((-3., 9., -3.), (6., 0, 0), (0, 0, 6.), b.DiffuseLight(12., 12., 12.))
+    cam = CameraConfig(40., 0., (0., 3., 9.), (0., 1., 0.), (0, 1, 0))
+    return b.finish(b.Bvh([model, glass, metal, light]), cam, (.3, .4, .6), rc)
+
+
+# ---- the reference's own scenes: every material, primitive and shader -------------------------------------------------
+def test_reference_test_scene_all_features():
+    """tests/scenes.rs:17-122: image texture, glass, rotated boxes, ConstantMedium, nested BVH, sphere + quad + triangle
+    lights, aperture 0.1."""
+    assert_parity(scenes.create_test_scene(RenderConfig(200, 100, 25)), 25)
+
+
+@pytest.mark.parametrize("shader", [AlbedoShader(), NormalShader(), SimpleShader()], ids=["albedo", "normal", "simple"])
+def test_single_hit_shaders(shader):
+    # shader.rs:129-215
+    assert_parity(scenes.create_test_scene(RenderConfig(200, 100, 4, shader)), 4)
+
+
+@pytest.mark.parametrize("blend", [0., .5, 1.])
+def test_blend_material(blend):
+    assert_parity(scenes.create_blend_material_scene(RenderConfig(128, 128, 16), blend), 16)
+
+
+def test_normal_mapping_quad_and_sphere():
+    assert_parity(scenes.create_normal_mapping_scene(RenderConfig(128, 128, 16), (30., 30., 30.), True), 16)
+    assert_parity(scenes.create_normal_mapping_sphere_scene(RenderConfig(128, 128, 16), (-30., 30., 30.)), 16)
+
+
+@pytest.mark.parametrize("half", [0.1, 0.8, None])
+def test_light_attenuation(half):
+    assert_parity(scenes.create_light_attenuation_scene(RenderConfig(128, 128, 16), half), 16)
+
+
+def test_uv_wrapping():
+    # triangle UVs outside [0,1] incl. negative (tests/scenes.rs:196-230)
+    assert_parity(scenes.create_uv_scene(RenderConfig(128, 128, 8)), 8)
+
+
+def test_bvh_bench_scene_with_and_without_nested_bvh():
+    # tests/scenes.rs:125-167: the same triangles as a nested Bvh or directly in the world give the same image
+    a = gpu_render(scenes.new_bvh_test_scene(RenderConfig(120, 60, 8), True, 300), 8)
+    b = gpu_render(scenes.new_bvh_test_scene(RenderConfig(120, 60, 8), False, 300), 8)
+    assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max()
+    assert_parity(scenes.new_bvh_test_scene(RenderConfig(120, 60, 8), True, 300), 8)
+
+
+# ---- reference golden images through the GPU ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,factory,w,h,ref_spp,_", CASES, ids=[c[0] for c in CASES])
+def test_gpu_matches_reference_golden(name, factory, w, h, ref_spp, _):
+    scene = factory(ref_spp)
+    sums = gpu_render(scene, ref_spp)
+    with np.errstate(invalid="ignore"):
+        actual = im.sums_to_rgb8(sums, ref_spp)
+    expected = np.asarray(Image.open(os.path.join(GOLDEN, f"out_expected_{name}.jpg")).convert("RGB"))
+    score = im.compare_output(actual, expected)
+    assert score > im.THRESHOLD, f"Comparison score for {name} is: {score}"
+
+
+# ---- edge cases -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(2, 2), (9, 5), (203, 97), (64, 8)])
+def test_ragged_image_sizes(w, h):
+    """Image sizes that are not multiples of the 8x8 work block, and the smallest legal image."""
+    assert_parity(scenes.cornell_box(RenderConfig(w, h, 20)), 20)
+
+
+@pytest.mark.parametrize("spp", [1, 15, 16, 17, 33])
+def test_sample_counts_around_the_chunk_size(spp):
+    assert_parity(scenes.cornell_box(RenderConfig(96, 96, spp)), spp)
+
+
+def test_sample_ranges_are_additive():
+    """sol_render ADDS samples [first, first+n): rendering [0,32) equals [0,16) then [16,32) bit for bit (chunk sums),
+    and a sample range rendered alone equals the oracle's same range."""
+    sc = scenes.cornell_box(RenderConfig(96, 96, 32))
+    with DeviceScene(sc) as ds:
+        ds.render(0, 32, pu.SEED)
+        whole = ds.read()
+        ds.clear()
+        ds.render(0, 16, pu.SEED)
+        ds.render(16, 16, pu.SEED)
+        parts = ds.read()
+        ds.clear()
+        ds.render(16, 7, pu.SEED)
+        mid = ds.read()
+    assert (whole == parts).all()
+    ref, _ = orc.render(sc, 16, 7, pu.SEED, real=orc.ORC_F32)
+    assert pu.compare(mid, ref, 7)["bad_pixels"] == 0
+
+
+def test_seed_changes_the_image_and_is_reproducible():
+    sc = scenes.cornell_box(RenderConfig(64, 64, 8))
+    a = gpu_render(sc, 8, seed=1)
+    b = gpu_render(sc, 8, seed=1)
+    c = gpu_render(sc, 8, seed=2)
+    assert (a == b).all() and (a != c).any()
+
+
+def test_max_depth_zero_and_one():
+    # depth >= max_depth is tested after the hit query (shader.rs:70-72): depth 0 -> black where anything is hit
+    for md in (0, 1, 3):
+        assert_parity(scenes.cornell_box(RenderConfig(64, 64, 8, PathTracingShader(md))), 8)
+
+
+def test_deep_tree_uses_the_spill_stack():
+    """A BVH nested 48 levels deep (Bvh::new([sphere, Bvh::new([sphere, ...])]), each nested Bvh inlined as a node) is deeper
+    than the 32-entry LDS stack: the overflow goes to the global spill area."""
+    b = SceneBuilder()
+    m = b.Lambertian(b.SolidColor(.8, .8, .8))
+    ids = [b.Sphere((float(x), 0.3 * (x % 3), 0.), 0.45, m) for x in range(50)]
+    inner = b.Bvh(ids[:2])
+    for k in range(2, 50):
+        inner = b.Bvh([inner, ids[k]]) if k % 2 else b.Bvh([ids[k], inner])
+    light = b.Sphere((0., 1e4, 0.), 3e3, b.DiffuseLight(3, 3, 3))
+    cam = CameraConfig(12., 0., (-30., 0.4, 0.3), (50., 0.3, 0.), (0, 1, 0))  # looks along the row: every level is entered
+    sc = b.finish(b.Bvh([inner, light]), cam, (.1, .1, .1), RenderConfig(64, 64, 4))
+    assert sc.tree_depth > 40
+    with DeviceScene(sc) as ds:
+        ds.render(0, 4, pu.SEED, counted=True)
+        img = ds.read()
+        st = ds.stats()
+    ref, _ = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F32)
+    assert pu.compare(img, ref, 4)["bad_pixels"] == 0
+    assert st["samples"] == 64 * 64 * 4 and st["rays"] >= st["samples"]
+    assert st["max_stack"] > 32, st  # the spill area was really used
+
+
+def test_errors_are_codes_not_crashes():
+    sc = scenes.cornell_box(RenderConfig(16, 16, 1))
+    with DeviceScene(sc) as ds:
+        with pytest.raises(DeviceError):
+            ds.set_partition(2, 2)
+        with pytest.raises(DeviceError):
+            ds.bind_accum(12345, 1)  # too small
+    with pytest.raises(DeviceError) as e:
+        DeviceScene(sc, device=99)
+    assert e.value.code == _abi.SOL_EDEVICE
+
+
+def test_counters_match_definitions():
+    sc = scenes.cornell_box(RenderConfig(64, 64, 4))
+    with DeviceScene(sc) as ds:
+        ds.render(0, 4, pu.SEED, counted=True)
+        st = ds.stats()
+        counted = ds.read()
+        ds.clear()
+        ds.render(0, 4, pu.SEED)
+        plain = ds.read()
+    assert (counted == plain).all()  # instrumentation does not change results
+    assert st["samples"] == 64 * 64 * 4
+    assert st["rays"] >= st["samples"] and st["node_visits"] > st["rays"] and st["quad_tests"] > 0
+    assert st["sphere_tests"] == 0 and st["triangle_tests"] == 0 and 1 <= st["max_stack"] <= 8
+
+
+# ---- multi-GPU sharding on one GPU: every rank's tiles, gathered, equal the single-GPU image ---------------------------
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_tile_partition_is_bit_identical(world):
+    import torch
+    sc = scenes.create_test_scene(RenderConfig(203, 97, 20))
+    whole = gpu_render(sc, 20)
+    with DeviceScene(sc) as ds:
+        ds.set_partition(0, world)
+        n = ds.accum_floats()
+        gathered = torch.zeros(world * n, dtype=torch.float32, device="cuda")
+        for r in range(world):
+            ds.set_partition(r, world)
+            assert ds.accum_floats() == n
+            ds.bind_accum(gathered.data_ptr() + r * n * 4, n)
+            ds.render(0, 20, pu.SEED)
+            ds.sync()
+            part = ds.read()  # other ranks' pixels are zero
+            owned = part.any(axis=-1)
+            assert (part[owned] == whole[owned]).all()
+        ds.set_partition(0, world)
+        image = torch.empty(sc.height * sc.width * 3, dtype=torch.float32, device="cuda")
+        ds.unpermute(gathered.data_ptr(), world, image.data_ptr())
+        ds.sync()
+        torch.cuda.synchronize()
+        out = image.cpu().numpy().reshape(sc.height, sc.width, 3)
+    assert (out == whole).all()
+
+
+def test_device_tonemap_matches_host_arithmetic():
+    import torch
+    sc = scenes.create_test_scene(RenderConfig(200, 100, 25))
+    with DeviceScene(sc) as ds:
+        ds.render(0, 25, pu.SEED)
+        sums = ds.read()
+        t = torch.from_numpy(sums).cuda()
+        rgb = ds.tonemap_rgb8(t.data_ptr(), 25)
+    with np.errstate(invalid="ignore"):
+        assert (rgb == im.sums_to_rgb8(sums, 25)).all()
+
+
+# ---- the host mirror: ray_trace(scene, output, abort) ---------------------------------------------------------------------
+def test_ray_trace_reports_progress_per_sample_and_final_image():
+    sc = scenes.create_test_scene(RenderConfig(200, 100, 25))
+    events, image = sc.ray_trace()
+    assert len(events) == 25 and abs(events[-1][0] - 1.0) < 1e-12
+    assert [e[3] for e in events].count(True) == 1 and events[-1][3]  # OnlyFinal: one image, in the last message
+    expected = np.asarray(Image.open(os.path.join(GOLDEN, "out_expected_pathTracing.jpg")).convert("RGB"))
+    assert im.compare_output(image, expected) > im.THRESHOLD
+    sums = gpu_render(sc, 25)
+    assert (image == im.sums_to_rgb8(sums, 25)).all()
+
+
+def test_ray_trace_every_sample_and_abort():
+    sc = scenes.cornell_box(RenderConfig(64, 64, 6))
+    events, image = sc.ray_trace(strategy="every_sample")
+    assert len(events) == 6 and all(e[3] for e in events)
+    n = [0]
+
+    def abort():
+        n[0] += 1
+        return n[0] > 2
+
+    events, image = sc.ray_trace(strategy="every_sample", abort=abort)
+    assert len(events) < 6  # aborted silently, Ok(()) like the reference (src/renderer/mod.rs:237-239)
+
+
+# ---- full BASELINE sizes: size-independent properties ------------------------------------------------------------------
+def test_full_size_c2_properties():
+    """configs[1] at its full size (1920x1080, 256 spp, 10 000 spheres): additivity over sample ranges, partition
+    independence on a strided subset, agreement of image statistics with the oracle's crop."""
+    sc = scenes.cornell_spheres(RenderConfig(1920, 1080, 256))
+    with DeviceScene(sc) as ds:
+        ds.render(0, 256, pu.SEED)
+        whole = ds.read()
+        ds.clear()
+        for f in range(0, 256, 64):
+            ds.render(f, 64, pu.SEED)
+        parts = ds.read()
+        ds.clear()
+        ds.set_partition(3, 8)
+        ds.render(0, 256, pu.SEED)
+        r3 = ds.read()
+    assert np.isfinite(whole).all() and (whole >= 0).all()
+    assert (whole == parts).all()
+    owned = r3.any(axis=-1)
+    assert 0.10 < owned.mean() < 0.14 and (r3[owned] == whole[owned]).all()
+    ref, _ = orc.render(sc, 0, 256, pu.SEED, real=orc.ORC_F32, rect=(960, 540, 992, 572))
+    assert pu.compare(whole, ref, 256, rect=(960, 540, 992, 572))["bad_pixels"] == 0
