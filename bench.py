@@ -38,6 +38,18 @@ def algorithmic_bytes(st, sizes):
             st["texel_fetches"] * 3 + st["samples"] * 12.0 / 16.0 * 3.0)  # 12 B chunk sum written, read, and added per 16 samples
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask, capped by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,11 +190,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             import orc  # TEST INFRASTRUCTURE, used here only as the timed CPU baseline
             t0 = time.time()
-            _, ost = orc.render(scene, 0, 1, SEED, real=orc.ORC_F64)
+            cores = host_cores()
+            _, ost = orc.render(scene, 0, 1, SEED, real=orc.ORC_F64, threads=cores)
             t1 = time.time() - t0
             n_spp = int(max(1, min(64, args.cpu_seconds / max(t1, 1e-3))))
             t0 = time.time()
-            _, ost = orc.render(scene, 1, n_spp, SEED, real=orc.ORC_F64)
+            _, ost = orc.render(scene, 1, n_spp, SEED, real=orc.ORC_F64, threads=cores)
             tc = time.time() - t0
             cpu_v = w * h * n_spp / tc / 1e6
             out["cpu_baseline"] = {"value": round(cpu_v, 4), "unit": "Msamples/s", "cores": int(ost["threads"]), "kind": "port",
