@@ -180,6 +180,9 @@ typedef struct SolStats {
   uint64_t shades;        /* material scatter evaluations                                               */
   uint64_t texel_fetches;
   uint64_t max_stack;     /* deepest traversal stack use                                                */
+  /* SIMD lane utilisation of the kernel's phases: [0]/[1] traverse, [2]/[3] shade, [4]/[5] generate, each pair =
+   * (active lanes summed over executions, 64 x executions). Instrumentation only. */
+  uint64_t phase[6];
 } SolStats;
 
 typedef struct SolScene SolScene; /* opaque handle: owns device memory, stream; one host thread at a time */
@@ -234,6 +237,11 @@ int sol_unpermute(SolScene* scene, const void* gathered_dev, int world, void* im
 int sol_tonemap_rgb8(SolScene* scene, const void* image_dev, uint32_t num_samples, uint8_t* rgb8_host);
 
 int sol_stats(const SolScene* scene, SolStats* out);
+
+/* Diagnostic: traces the single path (pixel x, y counted from the image top; sample index) and writes 12 floats per ray
+ * (origin xyz, direction xyz, hit t, hit reference bits, dfs index bits, depth, 0, 0), closed by a row holding the sample's
+ * colour in its first three floats and -1 in the fourth. For comparing a path bounce by bounce with the oracle. */
+int sol_debug_path(SolScene* scene, uint32_t x, uint32_t y, uint32_t sample, uint64_t seed, float* rows, uint32_t max_rows);
 
 /* Measurement: with timing enabled every sol_render brackets its render kernel with HIP events on the stream it is
  * launched on; sol_last_kernel_ms blocks on the last one and returns its duration (and the grid it was launched with).

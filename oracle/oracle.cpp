@@ -228,6 +228,7 @@ template <typename R> struct Scene {
   uint32_t root = 0, width = 0, height = 0, shader = 0, max_depth = 0;
   V3<R> background;
   V3<R> cam_origin, cam_llc, cam_h, cam_v, cam_u, cam_vv; R lens_radius = 0;
+  R box_pad = 0;  // fp32 box pad (0 in f64)
 
   static V3<R> cv(const double* p) { return {(R)p[0], (R)p[1], (R)p[2]}; }
   explicit Scene(const SolSceneDesc& d) {
@@ -252,6 +253,7 @@ template <typename R> struct Scene {
       for (int j = 0; j < 3; ++j) take(d.camera.origin[j]);
       pad = (R)(S * (1.0f / 1048576.0f));
     }
+    box_pad = pad;
     nodes.resize(d.n_nodes);
     for (uint32_t i = 0; i < d.n_nodes; ++i) {
       for (int k = 0; k < 6; k += 2) {
@@ -296,6 +298,7 @@ template <typename R> struct Scene {
 // Geometric part of a RayHit candidate (material/mod.rs:23-57 before get_transformed_normal)
 template <typename R> struct Cand {
   R t; V3<R> p; Onb<R> onb; UvF uv; bool front; int mat;
+  uint32_t ref = 0;  // the primitive that was hit (diagnostics)
 };
 
 struct Counters { uint64_t rays = 0, node_visits = 0, sphere_tests = 0, quad_tests = 0, tri_tests = 0, shades = 0, texels = 0, samples = 0; };
@@ -305,7 +308,9 @@ template <typename R> struct Tracer {
   Counters cnt;
   Rng rng;
   uint32_t cur_depth = 0;  // depth of the ray being searched (medium sub-stream key)
-  explicit Tracer(const Scene<R>& s) : sc(s) {}
+  std::vector<float>* trace = nullptr;  // diagnostics: 12 floats per ray (orc_debug_path)
+  R sphere_slack = 0;                   // half the fp32 box pad (float instantiation only)
+  explicit Tracer(const Scene<R>& s) : sc(s) { sphere_slack = s.box_pad * (R)0.5; }
 
   R rnd() { return u32_to_unit<R>(rng.next_u32()); }                 // random_normal_float (random.rs:4-6)
   R rnd_range(R mn, R mx) { return rnd() * (mx - mn) + mn; }         // random_float (random.rs:9-11)
@@ -381,10 +386,22 @@ template <typename R> struct Tracer {
     R disc = half_b * half_b - a * c;
     if (disc < (R)0) return false;
     R sqrt_d = std::sqrt(disc);
-    R root = (-half_b - sqrt_d) / a;
-    if (!contains(tmin, tmax, root)) {
-      root = (-half_b + sqrt_d) / a;
+    // fp32 contract: in the float instantiation a root also has to put its hit point inside the sphere's own
+    // box (centre +- radius, widened by half the box pad); the fp32 quadratic loses 7 digits for distant origins and would
+    // otherwise report points that lie outside every box bounding the sphere. In f64 (the reference) nothing is added.
+    auto root_ok = [&](R root) {
       if (!contains(tmin, tmax, root)) return false;
+      if (sizeof(R) == 4) {
+        const V3<R> p = r.at(root);
+        const R lim = S.radius + sphere_slack;
+        return std::fabs(p.x - S.center.x) <= lim && std::fabs(p.y - S.center.y) <= lim && std::fabs(p.z - S.center.z) <= lim;
+      }
+      return true;
+    };
+    R root = (-half_b - sqrt_d) / a;
+    if (!root_ok(root)) {
+      root = (-half_b + sqrt_d) / a;
+      if (!root_ok(root)) return false;
     }
     V3<R> hp = r.at(root);
     V3<R> n = hp - S.center;
@@ -442,10 +459,10 @@ template <typename R> struct Tracer {
         if (hit_ref(n.right, r, tmin, l.t, rr)) out = rr; else out = l;
         return true;
       }
-      case SOL_REF_SPHERE: return hit_sphere(sc.spheres[idx], r, tmin, tmax, out);
-      case SOL_REF_QUAD: return hit_quad(sc.quads[idx], r, tmin, tmax, out);
-      case SOL_REF_TRIANGLE: return hit_triangle(sc.tris[idx], r, tmin, tmax, out);
-      case SOL_REF_MEDIUM: return hit_medium(sc.meds[idx], idx, r, tmin, tmax, out);
+      case SOL_REF_SPHERE: if (!hit_sphere(sc.spheres[idx], r, tmin, tmax, out)) return false; out.ref = ref; return true;
+      case SOL_REF_QUAD: if (!hit_quad(sc.quads[idx], r, tmin, tmax, out)) return false; out.ref = ref; return true;
+      case SOL_REF_TRIANGLE: if (!hit_triangle(sc.tris[idx], r, tmin, tmax, out)) return false; out.ref = ref; return true;
+      case SOL_REF_MEDIUM: if (!hit_medium(sc.meds[idx], idx, r, tmin, tmax, out)) return false; out.ref = ref; return true;
     }
     return false;
   }
@@ -624,8 +641,15 @@ template <typename R> struct Tracer {
     cnt.rays++;
     cur_depth = depth;
     Cand<R> c;
-    if (!hit_ref(sc.root, ray, (R)RAY_MIN, std::numeric_limits<R>::infinity(), c))
-      return {sc.background, false, 0, 0};  // renderer/mod.rs:197-204
+    const bool any_hit = hit_ref(sc.root, ray, (R)RAY_MIN, std::numeric_limits<R>::infinity(), c);
+    if (trace) {
+      uint32_t rb = any_hit ? c.ref : 0u;
+      float rf; std::memcpy(&rf, &rb, 4);
+      const float row[12] = {(float)ray.origin.x, (float)ray.origin.y, (float)ray.origin.z, (float)ray.direction.x, (float)ray.direction.y,
+                             (float)ray.direction.z, any_hit ? (float)c.t : std::numeric_limits<float>::infinity(), rf, 0.f, (float)depth, 0.f, 0.f};
+      trace->insert(trace->end(), row, row + 12);
+    }
+    if (!any_hit) return {sc.background, false, 0, 0};  // renderer/mod.rs:197-204
     RayHit rec{c.p, {}, c.mat, c.t, c.uv, c.front};
     rec.normal = transformed_normal(c.mat, c.onb, c.uv);  // RayHit::new (material/mod.rs:50), closest hit only
     switch (sc.shader) {
@@ -785,6 +809,28 @@ void orc_f32_funcs(float r, float x, float y, float out[5]) {
   float c, s; sincos2pi(r, c, s);
   out[0] = c; out[1] = s; out[2] = acos_r(x); out[3] = atan2_r(y, x); out[4] = log_r(r);
 }
+// Diagnostic: the rays of one path (same row layout as the device's sol_debug_path; dfs column left 0).
+int orc_debug_path(const SolSceneDesc* d, int real_kind, uint32_t x, uint32_t y, uint32_t sample, uint64_t seed, float* rows, uint32_t max_rows) {
+  std::vector<float> tr;
+  float col[3];
+  if (real_kind == ORC_F32) {
+    Scene<float> sc(*d); Tracer<float> t(sc); t.trace = &tr;
+    V3<float> c = t.sample_pixel(x, (d->height - 1) - y, sample, seed);
+    col[0] = c.x; col[1] = c.y; col[2] = c.z;
+  } else {
+    Scene<double> sc(*d); Tracer<double> t(sc); t.trace = &tr;
+    V3<double> c = t.sample_pixel(x, (d->height - 1) - y, sample, seed);
+    col[0] = (float)c.x; col[1] = (float)c.y; col[2] = (float)c.z;
+  }
+  uint32_t n = (uint32_t)(tr.size() / 12);
+  if (n + 1 > max_rows) n = max_rows - 1;
+  std::memcpy(rows, tr.data(), (size_t)n * 12 * sizeof(float));
+  float* last = rows + (size_t)n * 12;
+  std::memset(last, 0, 12 * sizeof(float));
+  last[0] = col[0]; last[1] = col[1]; last[2] = col[2]; last[3] = -1.0f;
+  return (int)n;
+}
+
 // fp32 function table with the row layouts of the device's sol_eval (tests/test_gpu_functions.py compares bit for bit).
 int orc_eval_f32(uint32_t fn, const float* in, uint32_t n, uint32_t is, float* out, uint32_t os) {
   typedef V3<float> F3;
@@ -826,6 +872,7 @@ int orc_eval_f32(uint32_t fn, const float* in, uint32_t n, uint32_t is, float* o
       case 4: {
         Scene<float>::Sph S{{x[0], x[1], x[2]}, x[3], 0, 0};
         Cand<float> c;
+        tr.sphere_slack = x[12];
         bool h = tr.hit_sphere(S, Ray<float>::make({x[4], x[5], x[6]}, {x[7], x[8], x[9]}), x[10], x[11], c);
         y[0] = h ? 1.f : 0.f; y[1] = h ? c.t : 0.f;
         break;

@@ -36,6 +36,7 @@ void orc_rgb_to_vec3(const uint8_t p[3], double out[3]);
 void orc_to_rgb_color(const double col[3], uint32_t spp, uint8_t out[3]);
 uint32_t orc_rng_bits(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t counter);
 void orc_f32_funcs(float r, float x, float y, float out[5]);
+int orc_debug_path(const SolSceneDesc* d, int real_kind, uint32_t x, uint32_t y, uint32_t sample, uint64_t seed, float* rows, uint32_t max_rows);
 int orc_eval_f32(uint32_t fn, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride);
 int orc_closest_hit(const SolSceneDesc* d, int real_kind, const double o[3], const double dir[3], double* t_out, uint32_t* mat_out);
 

@@ -85,6 +85,17 @@ def render(scene, first_sample, n_samples, seed, real=ORC_F32, rect=None, thread
     return out, st.as_dict()
 
 
+def debug_path(scene, x, y, sample, seed, real=ORC_F32, max_rows=80):
+    """Rays of one path: rows of (o xyz, d xyz, t, ref bits, 0, depth, 0, 0); returns (rows, colour)."""
+    lib = load()
+    lib.orc_debug_path.restype = C.c_int
+    lib.orc_debug_path.argtypes = [C.POINTER(_abi.SolSceneDesc), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                   C.c_void_p, C.c_uint32]
+    buf = np.zeros((max_rows, 12), dtype=np.float32)
+    n = lib.orc_debug_path(scene.desc_ptr, real, x, y, sample, seed, buf.ctypes.data, max_rows)
+    return buf[:n], buf[n, :3].copy()
+
+
 def eval_f32(fn, rows, out_cols):
     """fp32 function table (same row layouts as the device's sol_eval)."""
     lib = load()

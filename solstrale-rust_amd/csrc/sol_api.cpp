@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -128,6 +129,10 @@ struct TreeBuilder {
     Box lb, rb;
     if (!resolve(n.left, depth + 1, lr, lb) || !resolve(n.right, depth + 1, rr, rb)) return false;
     on_path[i] = 0;
+#ifdef SOL_NO_LEAF_BOX  // debug variant: no extra per-primitive boxes in two-leaf nodes (the reference tests none)
+    if (lk != SOL_REF_NONE && lk != SOL_REF_NODE) lb = Box{{-F_INF, F_INF, -F_INF, F_INF, -F_INF, F_INF}};
+    if (rk != SOL_REF_NONE && rk != SOL_REF_NODE) rb = Box{{-F_INF, F_INF, -F_INF, F_INF, -F_INF, F_INF}};
+#endif
     DNode& dn = nodes[di];
     dn.lxmin = lb.v[0]; dn.lxmax = lb.v[1]; dn.lymin = lb.v[2]; dn.lymax = lb.v[3]; dn.lzmin = lb.v[4]; dn.lzmax = lb.v[5];
     dn.rxmin = rb.v[0]; dn.rxmax = rb.v[1]; dn.rymin = rb.v[2]; dn.rymax = rb.v[3]; dn.rzmin = rb.v[4]; dn.rzmax = rb.v[5];
@@ -137,6 +142,134 @@ struct TreeBuilder {
     out_ref = SOL_MAKE_REF(SOL_REF_NODE, di);
     out_box = cast_box(n.bbox);
     return true;
+  }
+};
+
+// Collapses the binary device tree into 8-wide nodes with 8-bit quantised child boxes (DWide, sol_types.h). Pure layout:
+// every decoded child box CONTAINS the child's padded fp32 box (checked with the device's own decode arithmetic), so the
+// wide tree culls no ray that the binary tree would not; closest hits (t, tie rule on dfs_index) are identical.
+struct WideBuilder {
+  const std::vector<DNode>& bin;
+  std::vector<DWide> out;
+  uint32_t max_depth = 0;
+  struct Child { uint32_t ref; Box box; };
+
+  explicit WideBuilder(const std::vector<DNode>& b) : bin(b) {}
+
+  static Box lbox(const DNode& n) { return Box{{n.lxmin, n.lxmax, n.lymin, n.lymax, n.lzmin, n.lzmax}}; }
+  static Box rbox(const DNode& n) { return Box{{n.rxmin, n.rxmax, n.rymin, n.rymax, n.rzmin, n.rzmax}}; }
+  static float area(const Box& b) {
+    float dx = b.v[1] - b.v[0], dy = b.v[3] - b.v[2], dz = b.v[5] - b.v[4];
+    if (!(dx >= 0.f && dy >= 0.f && dz >= 0.f)) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+  static float decode(float origin, uint32_t q, float scale) { return origin + (float)q * scale; }  // == device decode
+
+  // Returns the reference to use for binary node `ni`: a wide node, or - when the node has a single child - that child.
+  uint32_t build(uint32_t ni, uint32_t depth) {
+    std::vector<Child> c;
+    auto add = [&](uint32_t ref, const Box& b) { if (SOL_REF_KIND(ref) != SOL_REF_NONE) c.push_back(Child{ref, b}); };
+    add(bin[ni].left, lbox(bin[ni]));
+    add(bin[ni].right, rbox(bin[ni]));
+    while (c.size() < 8) {  // open the inner child with the largest surface until eight children (or only leaves) remain
+      int best = -1;
+      float best_a = -1.f;
+      for (size_t i = 0; i < c.size(); ++i)
+        if (SOL_REF_KIND(c[i].ref) == SOL_REF_NODE) {
+          const DNode& n = bin[SOL_REF_INDEX(c[i].ref)];
+          int kids = (SOL_REF_KIND(n.left) != SOL_REF_NONE) + (SOL_REF_KIND(n.right) != SOL_REF_NONE);
+          if (c.size() - 1 + kids > 8) continue;
+          float a = area(c[i].box);
+          if (a > best_a) { best_a = a; best = (int)i; }
+        }
+      if (best < 0) break;
+      const DNode n = bin[SOL_REF_INDEX(c[best].ref)];
+      c.erase(c.begin() + best);
+      add(n.left, lbox(n));
+      add(n.right, rbox(n));
+    }
+    const uint32_t wi = (uint32_t)out.size();
+    out.push_back(DWide{});
+    if (depth + 1 > max_depth) max_depth = depth + 1;
+    // node box and quantisation grid
+    float lo[3] = {F_INF, F_INF, F_INF}, hi[3] = {-F_INF, -F_INF, -F_INF};
+    for (auto& ch : c)
+      for (int a = 0; a < 3; ++a) {
+        if (std::isfinite(ch.box.v[2 * a])) lo[a] = std::min(lo[a], ch.box.v[2 * a] - g_box_pad);
+        if (std::isfinite(ch.box.v[2 * a + 1])) hi[a] = std::max(hi[a], ch.box.v[2 * a + 1] + g_box_pad);
+      }
+    uint32_t eb[3];
+    float scale[3];
+    for (int a = 0; a < 3; ++a) {
+      if (!(hi[a] >= lo[a])) { lo[a] = 0.f; hi[a] = 0.f; }
+      int e = 1;
+      float ext = hi[a] - lo[a];
+      if (ext > 0.f && std::isfinite(ext)) {
+        int ex;
+        std::frexp(ext / 255.0f, &ex);  // ext/255 = m * 2^ex, m in [0.5,1)  ->  2^ex >= ext/255
+        e = std::min(254, std::max(1, ex + 127));
+      }
+      eb[a] = (uint32_t)e;
+      uint32_t bits = eb[a] << 23;
+      std::memcpy(&scale[a], &bits, 4);
+    }
+    // slots by octant of the child's centre (x << 2 | y << 1 | z), nearest free slot on conflict
+    float ctr[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+    int slot_of[8];
+    bool used[8] = {false, false, false, false, false, false, false, false};
+    std::vector<size_t> order(c.size());
+    for (size_t i = 0; i < c.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return area(c[a].box) > area(c[b].box); });
+    for (size_t oi : order) {
+      const Box& b = c[oi].box;
+      int pref = ((0.5f * (b.v[0] + b.v[1]) > ctr[0]) ? 4 : 0) | ((0.5f * (b.v[2] + b.v[3]) > ctr[1]) ? 2 : 0) |
+                 ((0.5f * (b.v[4] + b.v[5]) > ctr[2]) ? 1 : 0);
+      int best = -1, best_d = 99;
+      for (int s = 0; s < 8; ++s)
+        if (!used[s]) {
+          int d = __builtin_popcount((unsigned)(s ^ pref));
+          if (d < best_d) { best_d = d; best = s; }
+        }
+      used[best] = true;
+      slot_of[oi] = best;
+    }
+    uint32_t q[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t refs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // empty slots: inverted box (lo = 255, hi = 0) and a NONE reference
+    for (int s = 0; s < 8; ++s)
+      if (!used[s])
+        for (int a = 0; a < 3; ++a) q[2 * a + (s >> 2)] |= 255u << (8 * (s & 3));
+    for (size_t i = 0; i < c.size(); ++i) {
+      const int s = slot_of[i];
+      for (int a = 0; a < 3; ++a) {
+        // one more box pad on top of the padded fp32 box: the device evaluates these planes in t-space (A + q * B), whose
+        // rounding error is up to ~0.7 pad; with the extra pad the margin is 3x
+        float cl = c[i].box.v[2 * a] - g_box_pad, chh = c[i].box.v[2 * a + 1] + g_box_pad;
+        if (!std::isfinite(cl)) cl = lo[a];
+        if (!std::isfinite(chh)) chh = hi[a];
+        long ql = (long)std::floor((cl - lo[a]) / scale[a]);
+        long qh = (long)std::ceil((chh - lo[a]) / scale[a]);
+        ql = std::min(255L, std::max(0L, ql));
+        qh = std::min(255L, std::max(0L, qh));
+        while (ql > 0 && decode(lo[a], (uint32_t)ql, scale[a]) > cl) --ql;      // conservative under the device's rounding
+        while (qh < 255 && decode(lo[a], (uint32_t)qh, scale[a]) < chh) ++qh;
+        if (decode(lo[a], (uint32_t)ql, scale[a]) > cl || decode(lo[a], (uint32_t)qh, scale[a]) < chh) {
+          // cannot happen: 255 * scale >= extent; be safe and open the box fully on this axis
+          ql = 0; qh = 255;
+        }
+        q[2 * a + (s >> 2)] |= (uint32_t)ql << (8 * (s & 3));
+        q[6 + 2 * a + (s >> 2)] |= (uint32_t)qh << (8 * (s & 3));
+      }
+      uint32_t r = c[i].ref;
+      if (SOL_REF_KIND(r) == SOL_REF_NODE) r = build(SOL_REF_INDEX(r), depth + 1);
+      refs[s] = r;
+    }
+    DWide& w = out[wi];
+    w.ox = lo[0]; w.oy = lo[1]; w.oz = lo[2];
+    w.meta = eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)c.size() << 24);
+    for (int k = 0; k < 12; ++k) w.q[k] = q[k];
+    for (int k = 0; k < 8; ++k) w.ref[k] = refs[k];
+    return SOL_MAKE_REF(SOL_REF_WIDE, wi);
   }
 };
 
@@ -157,7 +290,7 @@ struct SolScene {
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevScene S{};
   // owned device buffers
-  DNode* nodes = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
+  DNode* nodes = nullptr; DWide* wides = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
   DSphere* spheres = nullptr; DMedium* mediums = nullptr; DMat* mats = nullptr; DTex* texs = nullptr;
   uint8_t* texels = nullptr; uint32_t* lights = nullptr;
   float* acc_own = nullptr; float* acc = nullptr; size_t acc_floats = 0;
@@ -172,6 +305,14 @@ struct SolScene {
   int rank = 0, world = 1;
   uint32_t blocks_x = 0, blocks_y = 0, n_local_blocks = 0;
   int n_cu = 0;
+  int kernel_version = 0;          // 0 auto; SOL_KERNEL=v1|v2|v3 forces one (A/B comparisons)
+  void* pool = nullptr; size_t pool_bytes = 0;  // path-slot pool of the wavefront kernels
+  uint32_t pool_slots_override = 0;  // SOL_POOL_SLOTS (v2: slots per wave)
+  uint32_t* queue = nullptr; size_t queue_slots = 0;  // v3 ray queue
+  void* wf_ctr = nullptr; uint32_t* wf_ctr_host = nullptr;
+  uint32_t wf_slots = 4u << 20;       // SOL_WF_SLOTS: pool size of the two-kernel wavefront
+  uint32_t wf_min_items = 2u << 20;   // SOL_WF_MIN_ITEMS: jobs below this use the single-launch kernel
+  uint32_t last_rounds = 0; int last_version = 0;
   bool timing = false;  // sol_kernel_timing: HIP events around the render kernel on its own stream
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   uint32_t timed_launches = 0, last_grid = 0;
@@ -206,7 +347,7 @@ int sol_device_count(void) {
 }
 
 int sol_record_sizes(uint32_t out[6]) {
-  out[0] = sizeof(DNode); out[1] = sizeof(DSphere); out[2] = sizeof(DQuad); out[3] = sizeof(DTri);
+  out[0] = SOL_WORLD_BINARY ? sizeof(DNode) : sizeof(DWide); out[1] = sizeof(DSphere); out[2] = sizeof(DQuad); out[3] = sizeof(DTri);
   out[4] = sizeof(DTriShade); out[5] = sizeof(DMat);
   return SOL_OK;
 }
@@ -215,8 +356,9 @@ void sol_scene_destroy(SolScene* s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
-  void* ptrs[] = {s->nodes, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
-                  s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters};
+  void* ptrs[] = {s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
+                  s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters, s->pool, s->queue, s->wf_ctr};
+  if (s->wf_ctr_host) hipHostFree(s->wf_ctr_host);
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (s->ev_start) hipEventDestroy(s->ev_start);
@@ -362,7 +504,12 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
       if (SOL_REF_KIND(r) == SOL_REF_NODE) { stk.push_back(tb.nodes[SOL_REF_INDEX(r)].left); stk.push_back(tb.nodes[SOL_REF_INDEX(r)].right); }
     }
   }
-  const uint32_t tree_depth = world_depth + medium_depth + 2;
+  // 8-wide tree of the world (a visit may push up to 7 children)
+  WideBuilder wb(tb.nodes);
+  uint32_t wroot = root_ref;
+  if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) wroot = wb.build(SOL_REF_INDEX(root_ref), 0);
+  const uint32_t world_stack = SOL_WORLD_BINARY ? world_depth : 7u * wb.max_depth;
+  const uint32_t tree_depth = world_stack + medium_depth + 2;
   if (tree_depth > SOL_LDS_STACK + SOL_SPILL_STACK) return fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", tree_depth, SOL_LDS_STACK + SOL_SPILL_STACK);
 
   // ---- lights ----
@@ -387,7 +534,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   s->stream = s->own_stream;
   int rc;
-  if ((rc = upload(tb.nodes, &s->nodes)) || (rc = upload(tris, &s->tris)) || (rc = upload(tshade, &s->tri_shade)) ||
+  if ((rc = upload(tb.nodes, &s->nodes)) || (rc = upload(wb.out, &s->wides)) || (rc = upload(tris, &s->tris)) || (rc = upload(tshade, &s->tri_shade)) ||
       (rc = upload(quads, &s->quads)) || (rc = upload(spheres, &s->spheres)) || (rc = upload(mediums, &s->mediums)) ||
       (rc = upload(mats, &s->mats)) || (rc = upload(texs, &s->texs)) || (rc = upload(lights, &s->lights)))
     return rc;
@@ -400,13 +547,14 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   HIP_TRY(hipMalloc((void**)&s->rgb8, (size_t)d->width * d->height * 3));
 
   DevScene& S = s->S;
-  S.nodes = s->nodes; S.tris = s->tris; S.tri_shade = s->tri_shade; S.quads = s->quads; S.spheres = s->spheres;
+  S.nodes = s->nodes; S.wides = s->wides; S.wroot = wroot; S.tris = s->tris; S.tri_shade = s->tri_shade; S.quads = s->quads; S.spheres = s->spheres;
   S.mediums = s->mediums; S.mats = s->mats; S.texs = s->texs; S.texels = s->texels; S.lights = s->lights;
   S.n_lights = d->n_lights;
   S.root = root_ref;
   S.rxmin = root_box.v[0]; S.rxmax = root_box.v[1]; S.rymin = root_box.v[2]; S.rymax = root_box.v[3];
   S.rzmin = root_box.v[4]; S.rzmax = root_box.v[5];
   S.width = d->width; S.height = d->height; S.shader = d->shader_kind; S.max_depth = d->max_depth;
+  S.sphere_slack = g_box_pad * 0.5f;
   S.bgx = (float)d->background[0]; S.bgy = (float)d->background[1]; S.bgz = (float)d->background[2];
   const SolCamera& c = d->camera;
   S.cam = DCamera{(float)c.origin[0], (float)c.origin[1], (float)c.origin[2],
@@ -415,6 +563,13 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
                   (float)c.vertical[0], (float)c.vertical[1], (float)c.vertical[2],
                   (float)c.u[0], (float)c.u[1], (float)c.u[2], (float)c.v[0], (float)c.v[1], (float)c.v[2],
                   (float)c.lens_radius};
+  if (const char* kv = std::getenv("SOL_KERNEL")) {
+    if (kv[0] == 'v') kv++;
+    s->kernel_version = (kv[0] >= '1' && kv[0] <= '3') ? kv[0] - '0' : 0;
+  }
+  if (const char* ps = std::getenv("SOL_POOL_SLOTS")) s->pool_slots_override = (uint32_t)std::atoi(ps);
+  if (const char* ps = std::getenv("SOL_WF_SLOTS")) s->wf_slots = std::max(4096, std::atoi(ps));
+  if (const char* ps = std::getenv("SOL_WF_MIN_ITEMS")) s->wf_min_items = (uint32_t)std::max(0, std::atoi(ps));
   s->has_medium = d->n_mediums > 0;
   s->tree_depth = tree_depth;
   s->blocks_x = (d->width + SOL_TILE - 1) / SOL_TILE;
@@ -476,13 +631,62 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
   if (items > 0xFFFF0000ull) return fail(SOL_EINVAL, "too many work items in one call (%llu): split the sample range", (unsigned long long)items);
   P.n_items = (uint32_t)items;
   if (P.n_items == 0) return SOL_OK;
-  const int bpc = sol_render_blocks_per_cu(count, s->has_medium);
+  // kernel choice: 0 = auto (two-kernel wavefront for large jobs, one-path-per-lane kernel for small ones)
+  int version = s->kernel_version;
+  // Measured on MI355X (C3, 128 spp): v1 997, v2 905, v3 684 Msamples/s - the wavefront variants raise the traversal's lane
+  // occupancy (0.45 -> 0.67-0.73) but pay for it in state traffic, refill stalls and per-round tails, so v1 is the default.
+  if (version == 0) version = 1;
+  int bpc = version == 3 ? sol_wf_trace_blocks_per_cu(count, s->has_medium) : sol_render_blocks_per_cu(version, count, s->has_medium);
   uint32_t grid = (uint32_t)(s->n_cu * bpc);
   const uint32_t need_blocks = (P.n_items + SOL_WG - 1) / SOL_WG;
   if (grid > need_blocks) grid = need_blocks;
   P.total_threads = grid * SOL_WG;
+  const uint32_t lds_depth = version == 3 ? (uint32_t)sol_wf_lds_stack_depth() : (uint32_t)SOL_LDS_STACK;
+  if (version == 3) {
+    // one global pool: enough slots that the trace kernel has >= 16 rays per resident lane, never more than the items
+    uint64_t want = std::min<uint64_t>(P.n_items, s->wf_slots);
+    want = ((want + SOL_WG - 1) / SOL_WG) * SOL_WG;
+    P.pool_slots = (uint32_t)want;
+    const size_t need = sol_wf_pool_bytes(P.pool_slots);  // POOL_RECORDS float4 per slot
+    if (need > s->pool_bytes) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      if (s->pool) hipFree(s->pool);
+      s->pool = nullptr;
+      s->pool_bytes = 0;
+      HIP_TRY(hipMalloc(&s->pool, need));
+      s->pool_bytes = need;
+    }
+    if ((size_t)P.pool_slots > s->queue_slots) {  // item reservoirs: one uint2 per 64 slots (shade wave)
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      if (s->queue) hipFree(s->queue);
+      s->queue = nullptr;
+      s->queue_slots = 0;
+      HIP_TRY(hipMalloc((void**)&s->queue, (size_t)P.pool_slots / 64 * 8));
+      s->queue_slots = P.pool_slots;
+    }
+    if (!s->wf_ctr) {
+      HIP_TRY(hipMalloc(&s->wf_ctr, 64));
+      HIP_TRY(hipHostMalloc((void**)&s->wf_ctr_host, 64, hipHostMallocDefault));
+    }
+  } else if (version == 2) {
+    // pool of path slots: per wave a multiple of 64, enough that every wave has several rays per lane in flight
+    const uint32_t waves = grid * (SOL_WG / 64);
+    uint32_t per_wave = (P.n_items + waves - 1) / waves;
+    per_wave = ((per_wave + 63u) / 64u) * 64u;
+    P.pool_slots = std::min<uint32_t>(SOL_POOL_MAX, std::max<uint32_t>(64u, per_wave));
+    if (s->pool_slots_override) P.pool_slots = std::min<uint32_t>(SOL_POOL_MAX, ((s->pool_slots_override + 63u) / 64u) * 64u);
+    const size_t need = sol_pool_bytes_per_wave(P.pool_slots) * waves;
+    if (need > s->pool_bytes) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      if (s->pool) hipFree(s->pool);
+      s->pool = nullptr;
+      s->pool_bytes = 0;
+      HIP_TRY(hipMalloc(&s->pool, need));
+      s->pool_bytes = need;
+    }
+  }
   // spill stack only when the tree can out-grow the LDS stack
-  size_t spill_words = s->tree_depth > SOL_LDS_STACK ? (size_t)P.total_threads * (s->tree_depth - SOL_LDS_STACK) : 16;
+  size_t spill_words = s->tree_depth > lds_depth ? (size_t)P.total_threads * (s->tree_depth - lds_depth) : 16;
   if (spill_words > s->spill_words) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->spill) hipFree(s->spill);
@@ -506,9 +710,34 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
   HIP_TRY(hipMemsetAsync(s->work, 0, sizeof(uint32_t), s->stream));
   if (count) HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(DevCounters), s->stream));
   if (s->timing) HIP_TRY(hipEventRecord(s->ev_start, s->stream));
-  HIP_TRY(sol_launch_render(s->S, P, s->acc, s->partial, s->work, s->spill, s->counters, grid, count, s->has_medium, s->stream));
+  if (version == 3) {
+    // rounds of (shade, trace) until no slot holds work; the live-slot count is read back every few rounds
+    uint32_t* ctr = (uint32_t*)s->wf_ctr;  // WfCounters {work_next, slot_cursor, live, pad}
+    HIP_TRY(hipMemsetAsync(ctr, 0, 16, s->stream));
+    HIP_TRY(hipMemsetAsync((char*)s->pool + (size_t)P.pool_slots * 16, 0, (size_t)P.pool_slots * 16, s->stream));  // record 1: flags
+    HIP_TRY(hipMemsetAsync(s->queue, 0, (size_t)P.pool_slots / 64 * 8, s->stream));                              // reservoirs
+    const uint32_t check_every = 16;
+    uint32_t rounds = 0;
+    for (;;) {
+      HIP_TRY(hipMemsetAsync(ctr + 1, 0, 8, s->stream));  // slot_cursor, live
+      HIP_TRY(sol_launch_wf_shade(s->S, P, s->acc, s->partial, ctr, s->pool, s->queue, s->counters, count, s->stream));
+      HIP_TRY(sol_launch_wf_trace(s->S, P, ctr, s->pool, s->spill, s->counters, grid, count, s->has_medium, s->stream));
+      ++rounds;
+      if (rounds % check_every == 0) {
+        HIP_TRY(hipMemcpyAsync(s->wf_ctr_host, ctr, 16, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (s->wf_ctr_host[2] == 0) break;
+        if (rounds > 4000000u) return fail(SOL_EDEVICE, "wavefront did not drain");
+      }
+    }
+    s->last_rounds = rounds;
+  } else {
+    HIP_TRY(sol_launch_render(version, s->S, P, s->acc, s->partial, s->work, s->spill, s->pool, s->counters, grid, count,
+                              s->has_medium, s->stream));
+  }
   if (s->timing) { HIP_TRY(hipEventRecord(s->ev_stop, s->stream)); s->timed_launches++; }
   s->last_grid = grid;
+  s->last_version = version;
   if (P.n_chunks > 1) HIP_TRY(sol_launch_resolve(s->acc, s->partial, (uint32_t)slots3, P.n_chunks, s->stream));
   if (count) {
     DevCounters c;
@@ -517,6 +746,7 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
     s->stats.samples = c.samples; s->stats.rays = c.rays; s->stats.node_visits = c.node_visits;
     s->stats.sphere_tests = c.sphere_tests; s->stats.quad_tests = c.quad_tests; s->stats.triangle_tests = c.triangle_tests;
     s->stats.shades = c.shades; s->stats.texel_fetches = c.texel_fetches; s->stats.max_stack = c.max_stack;
+    for (int k = 0; k < 6; ++k) s->stats.phase[k] = c.phase[k];
   }
   return SOL_OK;
 }
@@ -577,6 +807,27 @@ int sol_eval(int device, uint32_t fn, const float* in, uint32_t n, uint32_t in_s
   hipFree(din);
   hipFree(dout);
   if (e != hipSuccess) return fail(SOL_EDEVICE, "sol_eval: %s", hipGetErrorString(e));
+  return SOL_OK;
+}
+
+int sol_debug_path(SolScene* s, uint32_t x, uint32_t y, uint32_t sample, uint64_t seed, float* rows, uint32_t max_rows) {
+  if (!s || !rows || max_rows < 2 || x >= s->S.width || y >= s->S.height) return fail(SOL_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  RenderParams P{};
+  P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
+  P.total_threads = 1;
+  float* dout = nullptr;
+  uint32_t* dspill = nullptr;
+  const size_t ob = (size_t)max_rows * 12 * sizeof(float);
+  HIP_TRY(hipMalloc((void**)&dout, ob));
+  hipError_t e = hipMalloc((void**)&dspill, (size_t)(SOL_SPILL_STACK + 8) * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(dout, 0, ob);
+  if (e == hipSuccess) e = sol_launch_debug_path(s->S, P, x, y, sample, dspill, dout, max_rows, s->has_medium, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(rows, dout, ob, hipMemcpyDeviceToHost);
+  hipFree(dout);
+  if (dspill) hipFree(dspill);
+  if (e != hipSuccess) return fail(SOL_EDEVICE, "sol_debug_path: %s", hipGetErrorString(e));
   return SOL_OK;
 }
 

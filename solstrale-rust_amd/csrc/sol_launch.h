@@ -1,12 +1,25 @@
-// sol_launch.h -- host-callable launch wrappers of sol_kernels.hip (internal to libsolstrale_hip.so).
+// sol_launch.h -- host-callable launch wrappers of sol_render.hip / sol_aux.hip (internal to libsolstrale_hip.so).
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "sol_types.h"
 
-hipError_t sol_launch_render(const DevScene& S, const RenderParams& P, float* acc, float* partial, uint32_t* work,
-                             uint32_t* spill, DevCounters* cnt, uint32_t grid, bool count, bool medium, hipStream_t stream);
-int sol_render_blocks_per_cu(bool count, bool medium);
+// version 1: one path per lane; version 2: wave-private wavefront over a pool of path slots (default)
+hipError_t sol_launch_render(int version, const DevScene& S, const RenderParams& P, float* acc, float* partial, uint32_t* work,
+                             uint32_t* spill, void* pool, DevCounters* cnt, uint32_t grid, bool count, bool medium,
+                             hipStream_t stream);
+int sol_render_blocks_per_cu(int version, bool count, bool medium);
+hipError_t sol_launch_debug_path(const DevScene& S, const RenderParams& P, uint32_t px, uint32_t py, uint32_t s, uint32_t* spill,
+                                 float* out, uint32_t max_rows, bool medium, hipStream_t stream);
+size_t sol_pool_bytes_per_wave(uint32_t slots);
+// version 3: two-kernel wavefront (one shade + one trace launch per round)
+hipError_t sol_launch_wf_shade(const DevScene& S, const RenderParams& P, float* acc, float* partial, void* ctr, void* rec,
+                               void* reservoir, DevCounters* cnt, bool count, hipStream_t stream);
+hipError_t sol_launch_wf_trace(const DevScene& S, const RenderParams& P, void* ctr, void* rec, uint32_t* spill, DevCounters* cnt,
+                               uint32_t grid, bool count, bool medium, hipStream_t stream);
+int sol_wf_trace_blocks_per_cu(bool count, bool medium);
+size_t sol_wf_pool_bytes(uint32_t slots);
+int sol_wf_lds_stack_depth();
 hipError_t sol_launch_resolve(float* acc, const float* partial, uint32_t n_floats, uint32_t n_chunks, hipStream_t stream);
 hipError_t sol_launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t blocks_x,
                                 uint32_t world, uint32_t only_rank, size_t stride, hipStream_t stream);

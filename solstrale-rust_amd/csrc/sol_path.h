@@ -1,0 +1,163 @@
+// sol_path.h -- one path vertex at a time: camera-ray generation and the flattened ray_color <-> shade recursion.
+// Shared by every render kernel so that all of them execute the identical fp32 operation sequence.
+#pragma once
+#include "sol_shade.h"
+
+// The recursion ray_color <-> shade (src/renderer/shader.rs:62-125) flattened exactly: with per-level factors a_d >= 0, a
+// composition of  x -> a*x  (ScatterBasic) and  x -> min(a*x, 3) with NaN -> 0  (ScatterPdf) is always x -> min(A*x, C);
+// a Pdf level does C <- min(C, 3*A), A <- A*a; a Basic level does A <- A*a (DESIGN.md "Flattened recursion").
+struct Path {
+  f3 o, d;        // current ray (Ray::new's cached reciprocal is recomputed where the ray is traced)
+  f3 A, C;
+  float acc_len;  // accumulated_ray_length (sum of parametric t, shader.rs:74)
+  uint32_t depth;
+  bool pdf_seen;
+  Rng rng;
+};
+
+// Pixel jitter + Camera::get_ray (src/renderer/mod.rs:263-265, src/camera.rs:77-89) for sample `s` of pixel (px, py),
+// py counted from the image top.
+template <bool COUNT>
+DEV void generate_path(const DevScene& S, uint32_t seed_lo, uint32_t seed_hi, uint32_t px, uint32_t py, uint32_t s, Path& p,
+                       Counters& cnt) {
+  rng_init(p.rng, seed_lo, seed_hi, py * S.width + px, s);
+  if (COUNT) cnt.samples++;
+  const uint32_t y_ref = (S.height - 1u) - py;
+  float u = ((float)px + rnd(p.rng)) / (float)(S.width - 1u);
+  float v = ((float)y_ref + rnd(p.rng)) / (float)(S.height - 1u);
+  f3 offset = mk3(0.f, 0.f, 0.f);
+  if (S.cam.lens_radius > 0.0f) {
+    f3 rd = mk3(0.f, 0.f, 0.f);
+    for (int it = 0; it < 80; ++it) {  // random_in_unit_disc (vec3.rs:400-412); the bound is never reached
+      rd.x = rnd_range(p.rng, -1.0f, 1.0f);
+      rd.y = rnd_range(p.rng, -1.0f, 1.0f);
+      if (len2(rd) < 1.0f) break;
+    }
+    rd = rd * S.cam.lens_radius;
+    offset = mk3(S.cam.ux, S.cam.uy, S.cam.uz) * rd.x + mk3(S.cam.wx, S.cam.wy, S.cam.wz) * rd.y;
+  }
+  const f3 org = mk3(S.cam.ox, S.cam.oy, S.cam.oz);
+  p.d = mk3(S.cam.llx, S.cam.lly, S.cam.llz) + mk3(S.cam.hx, S.cam.hy, S.cam.hz) * u + mk3(S.cam.vx, S.cam.vy, S.cam.vz) * v - org -
+        offset;
+  p.o = org + offset;
+  const float inf = __builtin_huge_valf();
+  p.A = mk3(1.f, 1.f, 1.f);
+  p.C = mk3(inf, inf, inf);
+  p.acc_len = 0.0f;
+  p.depth = 0;
+  p.pdf_seen = false;
+}
+
+DEV f3 ray_inverse(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }  // Ray::new (geo/mod.rs:277-285)
+
+// Processes the result `h` of world.hit(ray) for the path `p`. Returns true when the sample is finished, with its colour
+// (get_attenuated_color applied) in `contrib`; returns false when the path continues with the new ray in p.o / p.d.
+template <bool COUNT>
+DEV bool shade_vertex(const DevScene& S, Path& p, const Hit& h, f3& contrib, Counters& cnt) {
+  bool terminal = true;
+  f3 x = mk3(S.bgx, S.bgy, S.bgz);  // miss: background (src/renderer/mod.rs:197-204)
+  bool has_af = false;
+  float af = 0.0f, path_len = 0.0f;
+  if (SOL_REF_KIND(h.ref) != SOL_REF_NONE) {
+    phase_tick<COUNT>(cnt, 1);
+    Surface sf;
+    build_surface<COUNT>(S, p.o, p.d, h, p.rng, p.depth, sf);
+    sf.normal = transformed_normal<COUNT>(S, sf.mat, sf, p.rng, cnt);  // RayHit::new (material/mod.rs:50)
+    Scatter sc;
+    if (S.shader != SOL_SHADER_PATH_TRACING) {
+      if (S.shader == SOL_SHADER_NORMAL) {  // shader.rs:165-172
+        x = sf.normal;
+      } else {  // Albedo (shader.rs:141-151), Simple (shader.rs:192-214)
+        scatter<COUNT>(S, p.d, sf, p.rng, sc, cnt);
+        x = sc.color;
+        if (S.shader == SOL_SHADER_SIMPLE && sc.type != SCATTER_EMISSION)
+          x = sc.color * (dot3(sf.normal, mk3(1.f, 1.f, -1.f)) * 0.5f + 0.75f);
+      }
+    } else if (p.depth >= S.max_depth) {  // shader.rs:70-72
+      x = mk3(0.f, 0.f, 0.f);
+    } else {
+      const float total = sf.t + p.acc_len;  // shader.rs:74
+      scatter<COUNT>(S, p.d, sf, p.rng, sc, cnt);
+      if (sc.type == SCATTER_EMISSION) {  // shader.rs:78-84
+        x = sc.color; has_af = sc.has_af; af = sc.af; path_len = total;
+      } else {
+        bool go_on = true;
+        if (sc.type == SCATTER_PDF) {  // shader.rs:95-104 + filter :109-125
+          const f3 a = sc.color * sc.probability;
+          if (!(a.x > 0.0f || a.y > 0.0f || a.z > 0.0f)) {
+            // a == 0 (or NaN): this level returns exactly 0 whatever lies beyond it -> the sample contributes 0
+            x = mk3(0.f, 0.f, 0.f);
+            go_on = false;
+          } else {
+            p.C = mk3(fminf(p.C.x, p.A.x * 3.0f), fminf(p.C.y, p.A.y * 3.0f), fminf(p.C.z, p.A.z * 3.0f));
+            p.A = p.A * a;
+            p.pdf_seen = true;
+          }
+        } else {  // ScatterBasic (shader.rs:85-94)
+          p.A = p.A * sc.color;
+        }
+        if (go_on) {
+          terminal = false;
+          p.o = sf.p;
+          p.d = sc.dir;
+          p.acc_len = total;
+          p.depth++;
+        }
+      }
+    }
+  }
+  if (terminal) {
+    f3 c = x;
+    if (S.shader == SOL_SHADER_PATH_TRACING) {
+      c = p.A * x;
+      if (p.pdf_seen) {
+        c.x = isnan(c.x) ? 0.0f : fminf(c.x, p.C.x);
+        c.y = isnan(c.y) ? 0.0f : fminf(c.y, p.C.y);
+        c.z = isnan(c.z) ? 0.0f : fminf(c.z, p.C.z);
+      }
+      if (has_af) c = (c * 1.0f) / (1.0f + af * path_len);  // get_attenuated_color (material/mod.rs:127-131)
+    }
+    contrib = c;
+  }
+  return terminal;
+}
+
+// Work item -> pixel. Items are ordered so that an aligned run of 64 is one 8x8 pixel block of this rank.
+struct Item {
+  uint32_t px, py, slot, chunk;
+};
+DEV bool decode_item(const DevScene& S, const RenderParams& P, uint32_t item, Item& it) {
+  const uint32_t slots = P.n_local_blocks * 64u;
+  it.chunk = item / slots;
+  it.slot = item - it.chunk * slots;
+  const uint32_t lb = it.slot >> 6, pin = it.slot & 63u;
+  const uint32_t b = lb * P.world + P.rank;
+  const uint32_t by = b / P.blocks_x, bx = b - by * P.blocks_x;
+  it.px = bx * SOL_TILE + (pin & 7u);
+  it.py = by * SOL_TILE + (pin >> 3);
+  return it.px < S.width && it.py < S.height;  // false: padding pixel of an edge block
+}
+// Writes a finished chunk sum: straight into the accumulator when the call has one chunk, else into the partial plane.
+DEV void write_chunk(const RenderParams& P, float* __restrict__ acc, float* __restrict__ partial, uint32_t slot, uint32_t chunk,
+                     f3 sum) {
+  if (P.n_chunks == 1) {
+    float* a = acc + (size_t)slot * 3;
+    a[0] += sum.x; a[1] += sum.y; a[2] += sum.z;
+  } else {
+    float* a = partial + ((size_t)chunk * (P.n_local_blocks * 64u) + slot) * 3;
+    a[0] = sum.x; a[1] = sum.y; a[2] = sum.z;
+  }
+}
+
+DEV void flush_counters(const Counters& cnt, DevCounters* __restrict__ dcnt) {
+  atomicAdd(&dcnt->samples, (unsigned long long)cnt.samples);
+  atomicAdd(&dcnt->rays, (unsigned long long)cnt.rays);
+  atomicAdd(&dcnt->node_visits, (unsigned long long)cnt.node_visits);
+  atomicAdd(&dcnt->sphere_tests, (unsigned long long)cnt.sphere_tests);
+  atomicAdd(&dcnt->quad_tests, (unsigned long long)cnt.quad_tests);
+  atomicAdd(&dcnt->triangle_tests, (unsigned long long)cnt.triangle_tests);
+  atomicAdd(&dcnt->shades, (unsigned long long)cnt.shades);
+  atomicAdd(&dcnt->texel_fetches, (unsigned long long)cnt.texel_fetches);
+  atomicMax(&dcnt->max_stack, (unsigned long long)cnt.max_stack);
+  for (int k = 0; k < 6; ++k) atomicAdd(&dcnt->phase[k], (unsigned long long)cnt.phase[k]);
+}

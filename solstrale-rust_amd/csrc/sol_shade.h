@@ -132,7 +132,7 @@ DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Co
     const DSphere Sp = S.spheres[idx];
     if (COUNT) cnt.sphere_tests++;
     float t;
-    if (!sphere_test(Sp, origin, dir, RAY_MIN_F, inf, t)) return 0.0f;
+    if (!sphere_test(Sp, origin, dir, RAY_MIN_F, inf, S.sphere_slack, t)) return 0.0f;
     float cos_theta_max = sol_sqrt(1.0f - Sp.radius * Sp.radius / len2(mk3(Sp.cx, Sp.cy, Sp.cz) - origin));
     float solid_angle = 2.0f * SOL_PI * (1.0f - cos_theta_max);
     return 1.0f / solid_angle;

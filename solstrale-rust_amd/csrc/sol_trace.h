@@ -5,10 +5,17 @@
 // reference's right-hand search uses the inclusive interval [min, t_left], src/util/interval.rs:67-69). The cost
 // is not the reference's: children are visited near-first, boxes beyond the current best t are culled, and the
 // per-lane stack lives in LDS ([level][lane] layout: lane l always hits bank l%32, conflict-free).
+//
+// The search is written as a resumable stepper (Trav / trav_begin / trav_step) so that a render kernel can refill idle
+// lanes with new rays between steps; closest_hit() is the run-to-completion form.
 #pragma once
 #include "../../include/solstrale_hip.h"
 #include "sol_math.h"
 #include "sol_types.h"
+
+// The world (searches with t >= 0.001) is walked through the 8-wide quantised tree; -DSOL_WORLD_BINARY=true builds the
+// A/B variant that walks the 2-wide DNode tree instead (same results).
+#define SOL_WORLD_ROOT(S) (SOL_WORLD_BINARY ? (S).root : (S).wroot)
 
 #define REF_DONE 0xFFFFFFFFu
 #define ALMOST_ZERO_F 1e-8f  // src/geo/vec3.rs:21
@@ -23,22 +30,39 @@ struct Hit {
 
 struct Counters {
   uint32_t samples, rays, node_visits, sphere_tests, quad_tests, triangle_tests, shades, texel_fetches, max_stack;
+  uint32_t phase[6];  // lane-utilisation instrumentation: (active lanes, 64 per executing wave) for traverse / shade / generate
 };
 
+// Lane-utilisation instrumentation (COUNT builds only): every active lane counts itself, the first active lane of the
+// wave counts the 64 slots of this execution.
+template <bool COUNT>
+DEV void phase_tick(Counters& cnt, int ph) {
+  if (COUNT) {
+    cnt.phase[2 * ph]++;
+    const unsigned long long m = __ballot(1);
+    if ((int)__lane_id() == __ffsll((long long)m) - 1) cnt.phase[2 * ph + 1] += 64u;
+  }
+}
+
 struct Stack {
-  uint32_t* lds;     // base of this workgroup's [SOL_LDS_STACK][SOL_WG] array, already offset by the lane
+  uint32_t* lds;     // base of this workgroup's [depth][SOL_WG] array, already offset by the lane
   uint32_t* spill;   // base of the global spill area, already offset by the global thread id
   uint32_t stride;   // total threads (spill stride between levels)
+  int depth;         // entries per lane kept in LDS; deeper entries go to the spill area
 };
 DEV void stack_push(const Stack& s, int& sp, uint32_t v) {
-  if (sp < SOL_LDS_STACK) s.lds[sp * SOL_WG] = v;
-  else s.spill[(size_t)(sp - SOL_LDS_STACK) * s.stride] = v;
+  if (sp < s.depth) s.lds[sp * SOL_WG] = v;
+  else s.spill[(size_t)(sp - s.depth) * s.stride] = v;
   sp++;
+}
+DEV void stack_store(const Stack& s, int level, uint32_t v) {
+  if (level < s.depth) s.lds[level * SOL_WG] = v;
+  else s.spill[(size_t)(level - s.depth) * s.stride] = v;
 }
 DEV uint32_t stack_pop(const Stack& s, int& sp) {
   sp--;
-  if (sp < SOL_LDS_STACK) return s.lds[sp * SOL_WG];
-  return s.spill[(size_t)(sp - SOL_LDS_STACK) * s.stride];
+  if (sp < s.depth) return s.lds[sp * SOL_WG];
+  return s.spill[(size_t)(sp - s.depth) * s.stride];
 }
 
 // Aabb::hit (src/geo/mod.rs:159-188): slab test over [0, inf); fmaxf/fminf return the non-NaN operand like Rust's
@@ -87,8 +111,21 @@ DEV bool quad_test(const DQuad& Q, f3 o, f3 d, float tmin, float tmax, float& t,
   v = dot3(w, cross3(mk3(Q.ux, Q.uy, Q.uz), planar));
   return (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && v <= 1.0f);
 }
+// fp32 contract, spheres: a root counts only if its hit point lies inside the sphere's own box (centre +- radius, widened
+// by `slack` = half the box pad). In fp32 the quadratic suffers catastrophic cancellation for distant origins with
+// unnormalised directions (camera at 800 units, |d| = 800: half_b^2 and a*c agree to 7 digits), and reports "hits" whose
+// point is up to 0.02 units off the sphere - outside every box that bounds it. Whether such a phantom is seen would then
+// depend on which boxes a traversal happens to test. With this rule a hit is always inside all of its boxes, so every
+// conservative BVH layout (reference-shaped, two-leaf extra boxes, 8-wide quantised) returns the same hit. In f64 the rule
+// never fires.
+DEV bool sphere_root_ok(const DSphere& S, f3 o, f3 d, float root, float tmin, float tmax, float slack) {
+  if (!(tmin <= root && root <= tmax)) return false;
+  const f3 hp = o + d * root;
+  const float lim = S.radius + slack;
+  return fabsf(hp.x - S.cx) <= lim && fabsf(hp.y - S.cy) <= lim && fabsf(hp.z - S.cz) <= lim;
+}
 // Sphere::hit (src/hittable/sphere.rs:64-108), geometric part.
-DEV bool sphere_test(const DSphere& S, f3 o, f3 d, float tmin, float tmax, float& t) {
+DEV bool sphere_test(const DSphere& S, f3 o, f3 d, float tmin, float tmax, float slack, float& t) {
   f3 oc = o - mk3(S.cx, S.cy, S.cz);
   float a = len2(d);
   float half_b = dot3(oc, d);
@@ -97,9 +134,9 @@ DEV bool sphere_test(const DSphere& S, f3 o, f3 d, float tmin, float tmax, float
   if (disc < 0.0f) return false;
   float sqrt_d = sol_sqrt(disc);
   float root = (-half_b - sqrt_d) / a;
-  if (!(tmin <= root && root <= tmax)) {
+  if (!sphere_root_ok(S, o, d, root, tmin, tmax, slack)) {
     root = (-half_b + sqrt_d) / a;
-    if (!(tmin <= root && root <= tmax)) return false;
+    if (!sphere_root_ok(S, o, d, root, tmin, tmax, slack)) return false;
   }
   t = root;
   return true;
@@ -109,27 +146,212 @@ DEV bool better(float t, uint32_t dfs, const Hit& h) {
   return t < h.t || (t == h.t && (SOL_REF_KIND(h.ref) == SOL_REF_NONE || dfs > h.dfs));
 }
 
-template <bool COUNT, bool MEDIUM>
-DEV void closest_hit(const DevScene& S, f3 o, f3 d, f3 inv, float tmin, float tmax, uint32_t root, float bxmin,
-                     float bxmax, float bymin, float bymax, float bzmin, float bzmax, Hit& h, const Stack& st, int sp_base,
-                     const Rng& rng, uint32_t depth, Counters& cnt);
+// State of one closest-hit search.
+struct Trav {
+  f3 o, d, inv;
+  float tmin;
+  uint32_t cur;  // reference being visited, REF_DONE when the search is over
+  int sp, sp_base;
+  Hit h;
+};
+
+// Starts a search of `root` over [tmin, tmax]; (bxmin..bzmax) is root's own box, tested first when root is a node
+// (Bvh::hit, bvh.rs:166).
+DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, float bxmin, float bxmax, float bymin,
+                    float bymax, float bzmin, float bzmax, int sp_base) {
+  t.o = o; t.d = d; t.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // Ray::new (geo/mod.rs:277-285)
+  t.tmin = tmin;
+  t.h.t = tmax;
+  t.h.ref = SOL_MAKE_REF(SOL_REF_NONE, 0);
+  t.h.dfs = 0;
+  t.h.u = t.h.v = 0.0f;
+  t.sp = t.sp_base = sp_base;
+  t.cur = root;
+  // A ray with a NaN in its origin or direction cannot hit anything: every primitive test ends in a comparison with NaN,
+  // which is false (the reference returns None the same way, after visiting every box - Aabb::hit ignores NaN). Such rays
+  // occur a few times per 10^8 samples; without this exit one lane walks the whole tree and tests every primitive.
+  if (isnan(d.x) || isnan(d.y) || isnan(d.z) || isnan(o.x) || isnan(o.y) || isnan(o.z)) { t.cur = REF_DONE; return; }
+  if (SOL_REF_KIND(root) == SOL_REF_NODE || SOL_REF_KIND(root) == SOL_REF_WIDE) {
+    float te;
+    if (!slab(bxmin, bxmax, bymin, bymax, bzmin, bzmax, o, t.inv, __builtin_signbitf(t.inv.x), __builtin_signbitf(t.inv.y),
+              __builtin_signbitf(t.inv.z), te))
+      t.cur = REF_DONE;
+  }
+}
+
+template <bool COUNT>
+DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, float tmax, float& t_out, const Stack& st,
+                     int sp, const Rng& rng, uint32_t depth, Counters& cnt);
+
+// Decodes child `i` (compile-time) of a wide node and tests it; sets bit i of `hits` when the child must be visited.
+// The slab test runs in t-space: plane q of an axis is crossed at  t = A + q * B  with  A = (origin - o) * inv,
+// B = scale * inv  (one FMA per plane), and the near / far byte arrays of each axis are chosen once per node from the sign of
+// the ray direction. This is NOT the reference's (b - o) * inv sequence and need not be: the boxes are culls, and the
+// builder pads them by twice the fp32 box pad, three times the worst rounding error of this evaluation.
+// NaN (0 * inf for axis-parallel rays) is ignored by fmaxf / fminf, i.e. treated as "no constraint": conservative.
+#define SOL_WIDE_CHILD(i, nxw, nyw, nzw, fxw, fyw, fzw, refv)                                                          \
+  {                                                                                                                     \
+    const float tnx = fmaf((float)(((nxw) >> (8 * ((i) & 3))) & 0xFFu), bx, ax), tfx = fmaf((float)(((fxw) >> (8 * ((i) & 3))) & 0xFFu), bx, ax); \
+    const float tny = fmaf((float)(((nyw) >> (8 * ((i) & 3))) & 0xFFu), by, ay), tfy = fmaf((float)(((fyw) >> (8 * ((i) & 3))) & 0xFFu), by, ay); \
+    const float tnz = fmaf((float)(((nzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az), tfz = fmaf((float)(((fzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az); \
+    const float te = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));                                                         \
+    const float tx = fminf(fminf(tfx, tfy), tfz);                                                                       \
+    const bool hit = SOL_REF_KIND(refv) != SOL_REF_NONE && te <= tx && te <= cull_t;                                    \
+    hits |= hit ? (1u << (i)) : 0u;                                                                                     \
+    hm |= hit ? (1u << ((i) ^ oct)) : 0u;                                                                               \
+  }
+// Second pass: the nearest hit child (lowest order index) becomes the current reference, the others go on the stack so
+// that the nearest of them is on top (position = number of hit children that are farther).
+#define SOL_WIDE_PLACE(i, refv)                                                                  \
+  if (hits & (1u << (i))) {                                                                      \
+    const uint32_t k = (uint32_t)(i) ^ oct;                                                      \
+    if (k == first) t.cur = (refv);                                                              \
+    else stack_store(st, t.sp + (int)__popc(hm >> (k + 1u)), (refv));                           \
+  }
+
+// One step: visits the node or primitive t.cur, then moves to the next reference (near child, or popped from the stack).
+// BINARY selects which inner-node kind this search walks: the 2-wide DNode tree (constant-medium boundaries, whose
+// search interval includes negative t) or the 8-wide DWide tree (the world).
+template <bool COUNT, bool MEDIUM, bool BINARY>
+DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
+  const uint32_t cur = t.cur;
+  const uint32_t kind = SOL_REF_KIND(cur);
+  const uint32_t idx = SOL_REF_INDEX(cur);
+  phase_tick<COUNT>(cnt, 0);
+  if (!BINARY && kind == SOL_REF_WIDE) {
+    const bool sx = __builtin_signbitf(t.inv.x), sy = __builtin_signbitf(t.inv.y), sz = __builtin_signbitf(t.inv.z);
+    const uint32_t oct = (sx ? 4u : 0u) | (sy ? 2u : 0u) | (sz ? 1u : 0u);
+    const float4* wp = reinterpret_cast<const float4*>(S.wides + idx);
+    const float4 h = wp[0];
+    const uint4 qa = *reinterpret_cast<const uint4*>(wp + 1), qb = *reinterpret_cast<const uint4*>(wp + 2);
+    const uint4 qc = *reinterpret_cast<const uint4*>(wp + 3);
+    const uint4 ra = *reinterpret_cast<const uint4*>(wp + 4), rb = *reinterpret_cast<const uint4*>(wp + 5);
+    if (COUNT) cnt.node_visits++;
+    const uint32_t meta = __float_as_uint(h.w);
+    const float scx = __uint_as_float((meta & 0xFFu) << 23), scy = __uint_as_float(((meta >> 8) & 0xFFu) << 23);
+    const float scz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
+#ifdef SOL_NO_TCULL
+    const float cull_t = __builtin_huge_valf();
+#else
+    const float cull_t = t.h.t;  // t >= tmin > 0 in a world search
+#endif
+    uint32_t hits = 0u, hm = 0u;
+    // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
+    // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
+    // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
+    const float ivx = __builtin_amdgcn_fmed3f(t.inv.x, -1e30f, 1e30f), ivy = __builtin_amdgcn_fmed3f(t.inv.y, -1e30f, 1e30f);
+    const float ivz = __builtin_amdgcn_fmed3f(t.inv.z, -1e30f, 1e30f);
+    const float ax = (h.x - t.o.x) * ivx, bx = scx * ivx;
+    const float ay = (h.y - t.o.y) * ivy, by = scy * ivy;
+    const float az = (h.z - t.o.z) * ivz, bz = scz * ivz;
+    // q words: qa = {lo_x[0..3], lo_x[4..7], lo_y[0..3], lo_y[4..7]}, qb = {lo_z.., lo_z.., hi_x.., hi_x..},
+    //          qc = {hi_y.., hi_y.., hi_z.., hi_z..}; near = the plane the ray meets first on that axis
+    const uint32_t nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
+    const uint32_t ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
+    const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
+    SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, ra.x)
+    SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, ra.y)
+    SOL_WIDE_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, ra.z)
+    SOL_WIDE_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, ra.w)
+    SOL_WIDE_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, rb.x)
+    SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, rb.y)
+    SOL_WIDE_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, rb.z)
+    SOL_WIDE_CHILD(7, nx1, ny1, nz1, fx1, fy1, fz1, rb.w)
+    if (hm != 0u) {
+      const uint32_t first = (uint32_t)__ffs((int)hm) - 1u;
+      SOL_WIDE_PLACE(0, ra.x) SOL_WIDE_PLACE(1, ra.y) SOL_WIDE_PLACE(2, ra.z) SOL_WIDE_PLACE(3, ra.w)
+      SOL_WIDE_PLACE(4, rb.x) SOL_WIDE_PLACE(5, rb.y) SOL_WIDE_PLACE(6, rb.z) SOL_WIDE_PLACE(7, rb.w)
+      t.sp += (int)__popc(hm) - 1;
+      if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
+      return;
+    }
+  } else if (BINARY && kind == SOL_REF_NODE) {
+    const bool sx = __builtin_signbitf(t.inv.x), sy = __builtin_signbitf(t.inv.y), sz = __builtin_signbitf(t.inv.z);
+    const float4* np = reinterpret_cast<const float4*>(S.nodes + idx);
+    const float4 a = np[0], b = np[1], c = np[2];
+    const uint4 r = *reinterpret_cast<const uint4*>(np + 3);
+    if (COUNT) cnt.node_visits++;
+    // Culling: a box whose entry parameter lies beyond the best hit cannot hold a better one. The slab test clamps the
+    // entry to 0 (origin inside the box), and a search over (-inf, inf) (constant-medium boundary) accepts hits at
+    // negative t, so boxes entered at 0 are never culled.
+#ifdef SOL_NO_TCULL
+    const float cull_t = __builtin_huge_valf();
+#else
+    const float cull_t = fmaxf(t.h.t, 0.0f);
+#endif
+    float tl, tr;
+    bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, t.o, t.inv, sx, sy, sz, tl) && tl <= cull_t;
+    bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, t.o, t.inv, sx, sy, sz, tr) && tr <= cull_t;
+    if (t.tmin < 0.0f) {
+      // r.z bit0/bit1: that child's box is the primitive's own box, which the reference does not test (a two-leaf
+      // `Bvh` tests only its union box, bvh.rs:91-96). For t >= 0 the extra test is a sound cull; a primitive hit at
+      // negative t lies outside the forward slab, so here the child is taken whenever the node was reached.
+      if (r.z & 1u) { hl = true; tl = 0.0f; }
+      if (r.z & 2u) { hr = true; tr = 0.0f; }
+    }
+    if (hl && hr) {
+      const bool lfirst = tl <= tr;
+      stack_push(st, t.sp, lfirst ? r.y : r.x);
+      if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
+      t.cur = lfirst ? r.x : r.y;
+      return;
+    }
+    if (hl) { t.cur = r.x; return; }
+    if (hr) { t.cur = r.y; return; }
+  } else if (kind == SOL_REF_TRIANGLE) {
+    const float4* tp = reinterpret_cast<const float4*>(S.tris + idx);
+    const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+    DTri T;
+    T.v0x = p0.x; T.v0y = p0.y; T.v0z = p0.z; T.e1x = p0.w; T.e1y = p1.x; T.e1z = p1.y; T.e2x = p1.z; T.e2y = p1.w; T.e2z = p2.x;
+    const uint32_t dfs = __float_as_uint(p2.y);
+    if (COUNT) cnt.triangle_tests++;
+    float tt, u, v;
+    if (tri_test(T, t.o, t.d, t.tmin, t.h.t, tt, u, v) && better(tt, dfs, t.h)) { t.h.t = tt; t.h.ref = cur; t.h.dfs = dfs; t.h.u = u; t.h.v = v; }
+  } else if (kind == SOL_REF_SPHERE) {
+    const DSphere Sp = S.spheres[idx];
+    if (COUNT) cnt.sphere_tests++;
+    float tt;
+    if (sphere_test(Sp, t.o, t.d, t.tmin, t.h.t, S.sphere_slack, tt) && better(tt, Sp.dfs, t.h)) { t.h.t = tt; t.h.ref = cur; t.h.dfs = Sp.dfs; }
+  } else if (kind == SOL_REF_QUAD) {
+    const DQuad Q = S.quads[idx];
+    if (COUNT) cnt.quad_tests++;
+    float tt, u, v;
+    if (quad_test(Q, t.o, t.d, t.tmin, t.h.t, tt, u, v) && better(tt, Q.dfs, t.h)) { t.h.t = tt; t.h.ref = cur; t.h.dfs = Q.dfs; t.h.u = u; t.h.v = v; }
+  } else if (MEDIUM && kind == SOL_REF_MEDIUM) {
+    float tt;
+    const uint32_t dfs = S.mediums[idx].dfs;
+    if (medium_test<COUNT>(S, idx, t.o, t.d, t.tmin, t.h.t, tt, st, t.sp, rng, depth, cnt) && better(tt, dfs, t.h)) {
+      t.h.t = tt; t.h.ref = cur; t.h.dfs = dfs;
+    }
+  }
+  t.cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
+}
+
+// Run-to-completion form.
+template <bool COUNT, bool MEDIUM, bool BINARY>
+DEV void closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, uint32_t root, float bxmin, float bxmax,
+                     float bymin, float bymax, float bzmin, float bzmax, Hit& h, const Stack& st, int sp_base, const Rng& rng,
+                     uint32_t depth, Counters& cnt) {
+  Trav t;
+  trav_begin(t, o, d, tmin, tmax, root, bxmin, bxmax, bymin, bymax, bzmin, bzmax, sp_base);
+  while (t.cur != REF_DONE) trav_step<COUNT, MEDIUM, BINARY>(S, t, st, rng, depth, cnt);
+  h = t.h;
+}
 
 // ConstantMedium::hit (src/hittable/constant_medium.rs:35-79). Its draws come from the sub-stream
 // 0x40000000 + (depth<<20 | medium<<8) + i of the path's generator (DESIGN.md "RNG"), so the outcome does not
 // depend on when the tree search reaches the medium.
 template <bool COUNT>
-DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, f3 inv, float tmin, float tmax, float& t_out,
-                     const Stack& st, int sp, const Rng& rng, uint32_t depth, Counters& cnt) {
+DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, float tmax, float& t_out, const Stack& st,
+                     int sp, const Rng& rng, uint32_t depth, Counters& cnt) {
   const DMedium M = S.mediums[midx];
   const float inf = __builtin_huge_valf();
   Hit h1, h2;
-  h1.t = inf; h1.ref = 0; h1.dfs = 0; h1.u = h1.v = 0.f;
-  closest_hit<COUNT, false>(S, o, d, inv, -inf, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax, h1,
-                            st, sp, rng, depth, cnt);
+  closest_hit<COUNT, false, true>(S, o, d, -inf, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax, h1, st, sp,
+                            rng, depth, cnt);
   if (SOL_REF_KIND(h1.ref) == SOL_REF_NONE) return false;
-  h2.t = inf; h2.ref = 0; h2.dfs = 0; h2.u = h2.v = 0.f;
-  closest_hit<COUNT, false>(S, o, d, inv, h1.t + 0.0001f, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin,
-                            M.bzmax, h2, st, sp, rng, depth, cnt);
+  closest_hit<COUNT, false, true>(S, o, d, h1.t + 0.0001f, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax,
+                            h2, st, sp, rng, depth, cnt);
   if (SOL_REF_KIND(h2.ref) == SOL_REF_NONE) return false;
   float t1 = fmaxf(h1.t, tmin);
   float t2 = fminf(h2.t, tmax);
@@ -154,81 +376,4 @@ DEV f3 medium_normal(const Rng& rng, uint32_t midx, uint32_t depth) {
     if (len2(p) < 1.0f) break;
   }
   return unit3(p);
-}
-
-template <bool COUNT, bool MEDIUM>
-DEV void closest_hit(const DevScene& S, f3 o, f3 d, f3 inv, float tmin, float tmax, uint32_t root, float bxmin,
-                     float bxmax, float bymin, float bymax, float bzmin, float bzmax, Hit& h, const Stack& st, int sp_base,
-                     const Rng& rng, uint32_t depth, Counters& cnt) {
-  const bool sx = __builtin_signbitf(inv.x), sy = __builtin_signbitf(inv.y), sz = __builtin_signbitf(inv.z);
-  h.t = tmax;
-  h.ref = SOL_MAKE_REF(SOL_REF_NONE, 0);
-  h.dfs = 0;
-  h.u = h.v = 0.0f;
-  uint32_t cur = root;
-  if (SOL_REF_KIND(root) == SOL_REF_NODE) {  // Bvh::hit starts with its own box (bvh.rs:166)
-    float te;
-    if (!slab(bxmin, bxmax, bymin, bymax, bzmin, bzmax, o, inv, sx, sy, sz, te)) return;
-  }
-  int sp = sp_base;
-  for (;;) {
-    const uint32_t kind = SOL_REF_KIND(cur);
-    const uint32_t idx = SOL_REF_INDEX(cur);
-    if (kind == SOL_REF_NODE) {
-      const float4* np = reinterpret_cast<const float4*>(S.nodes + idx);
-      const float4 a = np[0], b = np[1], c = np[2];
-      const uint4 r = *reinterpret_cast<const uint4*>(np + 3);
-      if (COUNT) cnt.node_visits++;
-      // Culling: a box whose entry parameter lies beyond the best hit cannot hold a better one. The slab test clamps the
-      // entry to 0 (origin inside the box), and a search over (-inf, inf) (constant-medium boundary) accepts hits at
-      // negative t, so boxes entered at 0 are never culled.
-      const float cull_t = fmaxf(h.t, 0.0f);
-      float tl, tr;
-      bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, sx, sy, sz, tl) && tl <= cull_t;
-      bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, sx, sy, sz, tr) && tr <= cull_t;
-      if (tmin < 0.0f) {
-        // r.z bit0/bit1: that child's box is the primitive's own box, which the reference does not test (a two-leaf
-        // `Bvh` tests only its union box, bvh.rs:91-96). For t >= 0 the extra test is a sound cull; a primitive hit at
-        // negative t lies outside the forward slab, so here the child is taken whenever the node was reached.
-        if (r.z & 1u) { hl = true; tl = 0.0f; }
-        if (r.z & 2u) { hr = true; tr = 0.0f; }
-      }
-      if (hl && hr) {
-        const bool lfirst = tl <= tr;
-        stack_push(st, sp, lfirst ? r.y : r.x);
-        if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)sp);
-        cur = lfirst ? r.x : r.y;
-        continue;
-      }
-      if (hl) { cur = r.x; continue; }
-      if (hr) { cur = r.y; continue; }
-    } else if (kind == SOL_REF_TRIANGLE) {
-      const float4* tp = reinterpret_cast<const float4*>(S.tris + idx);
-      const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-      DTri T;
-      T.v0x = p0.x; T.v0y = p0.y; T.v0z = p0.z; T.e1x = p0.w; T.e1y = p1.x; T.e1z = p1.y; T.e2x = p1.z; T.e2y = p1.w; T.e2z = p2.x;
-      const uint32_t dfs = __float_as_uint(p2.y);
-      if (COUNT) cnt.triangle_tests++;
-      float t, u, v;
-      if (tri_test(T, o, d, tmin, h.t, t, u, v) && better(t, dfs, h)) { h.t = t; h.ref = cur; h.dfs = dfs; h.u = u; h.v = v; }
-    } else if (kind == SOL_REF_SPHERE) {
-      const DSphere Sp = S.spheres[idx];
-      if (COUNT) cnt.sphere_tests++;
-      float t;
-      if (sphere_test(Sp, o, d, tmin, h.t, t) && better(t, Sp.dfs, h)) { h.t = t; h.ref = cur; h.dfs = Sp.dfs; }
-    } else if (kind == SOL_REF_QUAD) {
-      const DQuad Q = S.quads[idx];
-      if (COUNT) cnt.quad_tests++;
-      float t, u, v;
-      if (quad_test(Q, o, d, tmin, h.t, t, u, v) && better(t, Q.dfs, h)) { h.t = t; h.ref = cur; h.dfs = Q.dfs; h.u = u; h.v = v; }
-    } else if (MEDIUM && kind == SOL_REF_MEDIUM) {
-      float t;
-      const uint32_t dfs = S.mediums[idx].dfs;
-      if (medium_test<COUNT>(S, idx, o, d, inv, tmin, h.t, t, st, sp, rng, depth, cnt) && better(t, dfs, h)) {
-        h.t = t; h.ref = cur; h.dfs = dfs;
-      }
-    }
-    if (sp == sp_base) break;
-    cur = stack_pop(st, sp);
-  }
 }

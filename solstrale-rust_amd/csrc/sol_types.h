@@ -6,9 +6,10 @@
 
 #define SOL_WG 256          // threads per workgroup = 4 wave64
 #define SOL_LDS_STACK 32    // traversal stack entries per lane kept in LDS (u32 each -> 32 KiB per workgroup)
-#define SOL_SPILL_STACK 96  // further entries per lane in a global spill area (deep trees, nested medium search)
+#define SOL_SPILL_STACK 480 // further entries per lane in a global spill area (deep trees, nested medium search)
 #define SOL_CHUNK 16        // samples per work item; fixed so that summation order never depends on the partition
 #define SOL_TILE 8          // 8x8-pixel blocks = one wave's worth of adjacent work items
+#define SOL_POOL_MAX 1024   // path slots per wave in the pool kernel (u16 queue entries: 2 KiB of LDS per wave)
 
 // 64-byte BVH node: the boxes of BOTH children plus their references, so one fetch (4 x dwordx4 per lane)
 // decides both children. Mirrors `Bvh{left,right,b_box}` (src/hittable/bvh.rs:14-18) with b_box hoisted.
@@ -19,6 +20,25 @@ struct __attribute__((aligned(16))) DNode {
   uint32_t left, right, pad0, pad1;  // SOL_MAKE_REF encoding, NODE index = device node index
 };
 static_assert(sizeof(DNode) == 64, "DNode");
+
+// 96-byte 8-wide node with 8-bit quantised child boxes, built at upload from the binary tree (sol_api.cpp, WideBuilder).
+// One visit costs 6 dwordx4 accesses per lane for 8 children, against 4 per 2 children for DNode - and the kernel is bound
+// by the CU's divergent lane-access rate (TA/TD busy 80-99 %, profiles/r01_ta_td_counters.json). Child i's box is
+//   lo = origin + q_lo[i] * scale,  hi = origin + q_hi[i] * scale,  scale_axis = 2^(e_axis - 127)
+// and CONTAINS the child's padded fp32 box (the builder checks the decoded values), so it is a pure cull: results do not
+// depend on it. Children sit in the slot whose index bits (x<<2 | y<<1 | z) match their octant of the node, so that
+// visiting slots in the order (k ^ ray_octant) is roughly front to back.
+#define SOL_REF_WIDE 6u  // device-only reference kind
+#ifndef SOL_WORLD_BINARY
+#define SOL_WORLD_BINARY false  // -DSOL_WORLD_BINARY=true: A/B variant that walks the 2-wide tree for the world as well
+#endif
+struct __attribute__((aligned(16))) DWide {
+  float ox, oy, oz;
+  uint32_t meta;      // ex | ey << 8 | ez << 16 (biased exponents of the scales) | child count << 24
+  uint32_t q[12];     // q_lo_x[8], q_lo_y[8], q_lo_z[8], q_hi_x[8], q_hi_y[8], q_hi_z[8]: one byte per child slot
+  uint32_t ref[8];    // child references (SOL_REF_NONE for an empty slot)
+};
+static_assert(sizeof(DWide) == 96, "DWide");
 
 // 48-byte triangle intersect record (src/hittable/triangle.rs:14-17 v0, v0v1, v0v2)
 struct __attribute__((aligned(16))) DTri {
@@ -98,6 +118,8 @@ struct DCamera {
 
 struct DevScene {
   const DNode* nodes;
+  const DWide* wides;   // 8-wide tree of the world (searches with t >= 0); binary nodes remain for medium boundaries
+  uint32_t wroot;       // reference of the world in the wide tree (kind SOL_REF_WIDE, or a primitive)
   const DTri* tris;
   const DTriShade* tri_shade;
   const DQuad* quads;
@@ -111,6 +133,7 @@ struct DevScene {
   uint32_t root;                                          // device reference of the world
   float rxmin, rxmax, rymin, rymax, rzmin, rzmax;         // world root box (Bvh::hit's own b_box test)
   uint32_t width, height, shader, max_depth;
+  float sphere_slack;  // half the fp32 box pad: tolerance of the sphere hit-point-in-own-box rule (sol_trace.h)
   float bgx, bgy, bgz;
   DCamera cam;
 };
@@ -123,8 +146,10 @@ struct RenderParams {
   uint32_t seed_lo, seed_hi;
   uint32_t n_items;          // n_chunks * n_local_blocks * 64
   uint32_t total_threads;    // grid * SOL_WG (spill stack stride)
+  uint32_t pool_slots;       // pool kernel: path slots per wave (multiple of 64, <= SOL_POOL_MAX)
 };
 
 struct DevCounters {
   unsigned long long samples, rays, node_visits, sphere_tests, quad_tests, triangle_tests, shades, texel_fetches, max_stack;
+  unsigned long long phase[6];
 };

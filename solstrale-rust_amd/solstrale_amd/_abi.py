@@ -9,7 +9,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(PKG_DIR))
-BUILD_DIR = os.path.join(os.path.dirname(PKG_DIR), "_build")
+BUILD_DIR = os.environ.get("SOLSTRALE_BUILD_DIR") or os.path.join(os.path.dirname(PKG_DIR), "_build")  # env: kernel A/B variants
 HIP_LIB = os.path.join(BUILD_DIR, "libsolstrale_hip.so")
 HOST_LIB = os.path.join(BUILD_DIR, "libsolstrale_host.so")
 
@@ -93,10 +93,15 @@ class SolSceneDesc(C.Structure):
 
 class SolStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "node_visits", "sphere_tests", "quad_tests",
-                                          "triangle_tests", "shades", "texel_fetches", "max_stack")]
+                                          "triangle_tests", "shades", "texel_fetches", "max_stack")] + \
+               [("phase", C.c_uint64 * 6)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "phase"}
+
+    def phases(self):
+        p = [int(x) for x in self.phase]
+        return {k: (p[2 * i] / p[2 * i + 1] if p[2 * i + 1] else 0.0) for i, k in enumerate(("traverse", "shade", "generate"))}
 
 
 ABI_STRUCTS = [SolAabb, SolBvhNode, SolSphere, SolQuad, SolTriangle, SolMedium, SolMaterial, SolTexture, SolCamera,
@@ -143,6 +148,7 @@ def load_hip():
     _sig(lib, "sol_stats", C.c_int, [P, C.POINTER(SolStats)])
     _sig(lib, "sol_record_sizes", C.c_int, [C.POINTER(C.c_uint32)])
     _sig(lib, "sol_last_error", C.c_char_p, [])
+    _sig(lib, "sol_debug_path", C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32])
     _sig(lib, "sol_kernel_timing", C.c_int, [P, C.c_int])
     _sig(lib, "sol_last_kernel_ms", C.c_int, [P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)])
     _sig(lib, "sol_eval", C.c_int, [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32])
@@ -153,7 +159,8 @@ def load_hip():
 HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol_scene_set_partition",
                "sol_accum_floats", "sol_accum_ptr", "sol_scene_bind_accum", "sol_scene_set_stream", "sol_clear",
                "sol_render", "sol_render_counted", "sol_sync", "sol_read", "sol_unpermute", "sol_tonemap_rgb8",
-               "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms"]
+               "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms",
+               "sol_debug_path"]
 
 
 def load_host():

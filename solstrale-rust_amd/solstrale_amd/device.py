@@ -108,6 +108,13 @@ class DeviceScene:
                                             out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
+    def debug_path(self, x, y, sample, seed, max_rows=80):
+        """Rays of one path: rows of (o xyz, d xyz, t, ref bits, dfs bits, depth, 0, 0); returns (rows, colour)."""
+        buf = np.zeros((max_rows, 12), dtype=np.float32)
+        self._chk(self.lib.sol_debug_path(self.h, x, y, sample, seed, buf.ctypes.data, max_rows))
+        n = int(np.argmax(buf[:, 3] == -1.0)) if (buf[:, 3] == -1.0).any() else max_rows - 1
+        return buf[:n], buf[n, :3].copy()
+
     def kernel_timing(self, enable=True):
         self._chk(self.lib.sol_kernel_timing(self.h, 1 if enable else 0))
 
@@ -115,6 +122,11 @@ class DeviceScene:
         ms, grid = C.c_float(), C.c_uint32()
         self._chk(self.lib.sol_last_kernel_ms(self.h, C.byref(ms), C.byref(grid)))
         return float(ms.value), int(grid.value)
+
+    def phase_stats(self):
+        st = _abi.SolStats()
+        self._chk(self.lib.sol_stats(self.h, C.byref(st)))
+        return st.phases()
 
     def stats(self):
         st = _abi.SolStats()

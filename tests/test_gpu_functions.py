@@ -81,10 +81,14 @@ def test_sphere_hit():
     o = r.uniform(-60, 60, (N, 3))
     d = (c + r.standard_normal((N, 3)) * rad * 0.8) - o  # mostly hitting
     d *= r.uniform(0.1, 30, (N, 1))
-    x = np.concatenate([c, rad, o, d, np.full((N, 1), 0.001), np.full((N, 1), np.inf)], 1).astype(np.float32)
+    # column 12: slack of the hit-point-in-own-box rule (fp32 contract)
+    x = np.concatenate([c, rad, o, d, np.full((N, 1), 0.001), np.full((N, 1), np.inf), np.full((N, 1), 4e-4)], 1).astype(np.float32)
     o2 = x.copy()
     o2[: N // 4, 4:7] = (c + rad * (d / np.linalg.norm(d, axis=1, keepdims=True)))[: N // 4]  # origins on the surface
-    for rows in (x, o2):
+    far = x.copy()  # distant origins with long directions: the regime where the fp32 quadratic loses its digits
+    far[:, 4:7] = (c - d / np.linalg.norm(d, axis=1, keepdims=True) * 900.0).astype(np.float32)
+    far[:, 7:10] = (d / np.linalg.norm(d, axis=1, keepdims=True) * 800.0 + r.standard_normal((N, 3)) * rad * 0.9).astype(np.float32)
+    for rows in (x, o2, far):
         g, cc = eval_functions(4, rows, 2), orc.eval_f32(4, rows, 2)
         _same(g, cc, "sphere hit")
         assert g[:, 0].mean() > 0.2

@@ -78,6 +78,23 @@ def _atrium_with_bsdfs(rc):
     return b.finish(b.Bvh([model, glass, metal, light]), cam, (.3, .4, .6), rc)
 
 
+def test_sphere_phantom_hits_are_layout_independent():
+    """Regression: camera rays with one direction component near zero grazing a sphere. The fp32 sphere quadratic (origin 800
+    units away, |d| = 800) reports points up to 0.02 units off the sphere; before the hit-point-in-own-box rule of the fp32
+    contract, whether such a phantom was seen depended on which boxes a traversal tested (reference tree vs extra leaf boxes
+    vs 8-wide quantised boxes) - found as 5 pixels of 2 073 600 differing at 64 spp. The paths must match ray for ray."""
+    sc = scenes.cornell_spheres(RenderConfig(1920, 1080, 64))
+    cases = [(958, 309, 32), (754, 539, 37), (959, 472, 35), (961, 165, 47), (959, 471, 63)]
+    with DeviceScene(sc) as ds:
+        for (x, y, s) in cases:
+            g, gc = ds.debug_path(x, y, s, pu.SEED)
+            o, oc = orc.debug_path(sc, x, y, s, pu.SEED)
+            n = len(g)  # the device stops a path whose throughput became exactly 0; the reference traces on (result 0 either way)
+            assert 1 <= n <= len(o), (x, y, s, len(g), len(o))
+            assert (g[:, :8].view(np.uint32) == o[:n, :8].view(np.uint32)).all(), (x, y, s)
+            assert np.abs(gc - oc).max() <= 1e-5 * max(1e-3, np.abs(oc).max())
+
+
 # ---- the reference's own scenes: every material, primitive and shader -------------------------------------------------
 def test_reference_test_scene_all_features():
     """tests/scenes.rs:17-122: image texture, glass, rotated boxes, ConstantMedium, nested BVH, sphere + quad + triangle
@@ -223,7 +240,7 @@ def test_counters_match_definitions():
     assert (counted == plain).all()  # instrumentation does not change results
     assert st["samples"] == 64 * 64 * 4
     assert st["rays"] >= st["samples"] and st["node_visits"] > st["rays"] and st["quad_tests"] > 0
-    assert st["sphere_tests"] == 0 and st["triangle_tests"] == 0 and 1 <= st["max_stack"] <= 8
+    assert st["sphere_tests"] == 0 and st["triangle_tests"] == 0 and 1 <= st["max_stack"] <= 21  # <= 7 per 8-wide level
 
 
 # ---- multi-GPU sharding on one GPU: every rank's tiles, gathered, equal the single-GPU image ---------------------------
