@@ -152,6 +152,11 @@ struct WideBuilder {
   const std::vector<DNode>& bin;
   std::vector<DWide> out;
   uint32_t max_depth = 0;
+  // surface-area estimate of a random ray's work: summed box areas of the children that are wide nodes / primitives
+  // (a child is visited with probability ~ its area / the root's area)
+  bool slot_by_assignment = !(std::getenv("SOL_SLOTS") && std::strcmp(std::getenv("SOL_SLOTS"), "octant") == 0);
+  double inner_area = 0., leaf_area = 0.;
+  double cost() const { return 2.5 * inner_area + leaf_area; }  // a wide-node visit costs ~2.5 primitive tests (instructions)
   struct Child { uint32_t ref; Box box; };
 
   explicit WideBuilder(const std::vector<DNode>& b) : bin(b) {}
@@ -191,6 +196,7 @@ struct WideBuilder {
     const uint32_t wi = (uint32_t)out.size();
     out.push_back(DWide{});
     if (depth + 1 > max_depth) max_depth = depth + 1;
+    for (auto& ch : c) (SOL_REF_KIND(ch.ref) == SOL_REF_NODE ? inner_area : leaf_area) += (double)area(ch.box);
     // node box and quantisation grid
     float lo[3] = {F_INF, F_INF, F_INF}, hi[3] = {-F_INF, -F_INF, -F_INF};
     for (auto& ch : c)
@@ -217,21 +223,65 @@ struct WideBuilder {
     float ctr[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
     int slot_of[8];
     bool used[8] = {false, false, false, false, false, false, false, false};
-    std::vector<size_t> order(c.size());
-    for (size_t i = 0; i < c.size(); ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return area(c[a].box) > area(c[b].box); });
-    for (size_t oi : order) {
-      const Box& b = c[oi].box;
-      int pref = ((0.5f * (b.v[0] + b.v[1]) > ctr[0]) ? 4 : 0) | ((0.5f * (b.v[2] + b.v[3]) > ctr[1]) ? 2 : 0) |
-                 ((0.5f * (b.v[4] + b.v[5]) > ctr[2]) ? 1 : 0);
-      int best = -1, best_d = 99;
-      for (int s = 0; s < 8; ++s)
-        if (!used[s]) {
-          int d = __builtin_popcount((unsigned)(s ^ pref));
-          if (d < best_d) { best_d = d; best = s; }
+    if (slot_by_assignment) {
+      // The device visits the hit children in the order slot ^ ray_octant, i.e. slot s is "far" along direction
+      // (+-1, +-1, +-1)_s. Give child i slot s so that the summed projections of the child centres on their slots'
+      // directions is largest (an 8x8 assignment problem, solved exactly: Kuhn-Munkres with potentials).
+      const int n = (int)c.size(), m = 8;
+      double cost[9][9];
+      for (int i = 1; i <= n; ++i) {
+        const Box& b = c[i - 1].box;
+        const double off[3] = {0.5 * ((double)b.v[0] + b.v[1]) - ctr[0], 0.5 * ((double)b.v[2] + b.v[3]) - ctr[1],
+                               0.5 * ((double)b.v[4] + b.v[5]) - ctr[2]};
+        for (int s = 0; s < m; ++s) {
+          double d = ((s & 4) ? off[0] : -off[0]) + ((s & 2) ? off[1] : -off[1]) + ((s & 1) ? off[2] : -off[2]);
+          cost[i][s + 1] = std::isfinite(d) ? -d : 0.;
         }
-      used[best] = true;
-      slot_of[oi] = best;
+      }
+      double u[9] = {0}, v[9] = {0};
+      int p[9] = {0}, way[9] = {0};
+      for (int i = 1; i <= n; ++i) {
+        p[0] = i;
+        int j0 = 0;
+        double minv[9];
+        bool usedc[9];
+        for (int j = 0; j <= m; ++j) { minv[j] = std::numeric_limits<double>::infinity(); usedc[j] = false; }
+        do {
+          usedc[j0] = true;
+          const int i0 = p[j0];
+          double delta = std::numeric_limits<double>::infinity();
+          int j1 = 0;
+          for (int j = 1; j <= m; ++j)
+            if (!usedc[j]) {
+              const double cur = cost[i0][j] - u[i0] - v[j];
+              if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+              if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+            }
+          for (int j = 0; j <= m; ++j)
+            if (usedc[j]) { u[p[j]] += delta; v[j] -= delta; } else minv[j] -= delta;
+          j0 = j1;
+        } while (p[j0] != 0);
+        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+      }
+      for (int j = 1; j <= m; ++j)
+        if (p[j] > 0) { slot_of[p[j] - 1] = j - 1; used[j - 1] = true; }
+    } else {
+      std::vector<size_t> order(c.size());
+      for (size_t i = 0; i < c.size(); ++i) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return area(c[a].box) > area(c[b].box); });
+      for (size_t oi : order) {
+        const Box& b = c[oi].box;
+        int pref = ((0.5f * (b.v[0] + b.v[1]) > ctr[0]) ? 4 : 0) | ((0.5f * (b.v[2] + b.v[3]) > ctr[1]) ? 2 : 0) |
+                   ((0.5f * (b.v[4] + b.v[5]) > ctr[2]) ? 1 : 0);
+        int best = -1, best_d = 99;
+        for (int s = 0; s < 8; ++s)
+          if (!used[s]) {
+            int d = __builtin_popcount((unsigned)(s ^ pref));
+            if (d < best_d) { best_d = d; best = s; }
+          }
+        used[best] = true;
+        slot_of[oi] = best;
+      }
     }
     uint32_t q[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t refs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -273,6 +323,119 @@ struct WideBuilder {
   }
 };
 
+// Rebuilds the WORLD's binary tree over the same primitives with a binned surface-area heuristic. The closest hit of a
+// search does not depend on the tree (every box bounds its primitives, ties are decided by the primitives' dfs_index in
+// the REFERENCE tree, which stays on the records), so the device is free to walk a better tree than the reference's
+// centroid-median one (bvh.rs:118-162); only the world search (t >= 0.001) uses it, constant-medium boundaries keep the
+// reference-shaped tree and its negative-t rules. Output has TreeBuilder's format (child boxes in the parent).
+struct SahBuilder {
+  struct Prim { uint32_t ref; Box box; float c[3]; };
+  std::vector<Prim> prims;
+  std::vector<DNode> nodes;
+  static constexpr int BINS = 16;
+
+  // Leaves of the reference-shaped device tree under `root` (a shared sub-tree contributes its leaves once per use).
+  bool collect(const std::vector<DNode>& bin, uint32_t root) {
+    std::vector<std::pair<uint32_t, Box>> stk;
+    stk.push_back({root, empty_box()});
+    while (!stk.empty()) {
+      auto [ref, box] = stk.back();
+      stk.pop_back();
+      const uint32_t k = SOL_REF_KIND(ref);
+      if (k == SOL_REF_NONE) continue;
+      if (k == SOL_REF_NODE) {
+        const DNode& n = bin[SOL_REF_INDEX(ref)];
+        stk.push_back({n.right, WideBuilder::rbox(n)});
+        stk.push_back({n.left, WideBuilder::lbox(n)});
+        continue;
+      }
+      Prim p{ref, box, {0.f, 0.f, 0.f}};
+      for (int a = 0; a < 3; ++a) {
+        if (!std::isfinite(box.v[2 * a]) || !std::isfinite(box.v[2 * a + 1]) || box.v[2 * a] > box.v[2 * a + 1]) return false;
+        p.c[a] = 0.5f * (box.v[2 * a] + box.v[2 * a + 1]);
+      }
+      if (prims.size() >= (1u << 26)) return false;
+      prims.push_back(p);
+    }
+    return prims.size() >= 2;
+  }
+  static void grow(Box& b, const Box& o) {
+    for (int a = 0; a < 3; ++a) { b.v[2 * a] = std::min(b.v[2 * a], o.v[2 * a]); b.v[2 * a + 1] = std::max(b.v[2 * a + 1], o.v[2 * a + 1]); }
+  }
+  static double area(const Box& b) {
+    double dx = (double)b.v[1] - b.v[0], dy = (double)b.v[3] - b.v[2], dz = (double)b.v[5] - b.v[4];
+    if (!(dx >= 0. && dy >= 0. && dz >= 0.)) return 0.;
+    return dx * dy + dy * dz + dz * dx;
+  }
+  // Builds [lo, hi) and returns its reference and box.
+  uint32_t build(size_t lo, size_t hi, uint32_t depth, Box& out_box) {
+    if (hi - lo == 1) { out_box = prims[lo].box; return prims[lo].ref; }
+    float cmin[3] = {F_INF, F_INF, F_INF}, cmax[3] = {-F_INF, -F_INF, -F_INF};
+    for (size_t i = lo; i < hi; ++i)
+      for (int a = 0; a < 3; ++a) { cmin[a] = std::min(cmin[a], prims[i].c[a]); cmax[a] = std::max(cmax[a], prims[i].c[a]); }
+    int best_axis = -1, best_bin = -1;
+    double best_cost = std::numeric_limits<double>::infinity();
+    float best_k = 0.f;
+    if (depth < 48)
+      for (int a = 0; a < 3; ++a) {
+        const float ext = cmax[a] - cmin[a];
+        if (!(ext > 0.f)) continue;
+        const float k = (float)BINS / ext;
+        Box bb[BINS];
+        uint32_t bn[BINS];
+        for (int b = 0; b < BINS; ++b) { bb[b] = empty_box(); bn[b] = 0; }
+        for (size_t i = lo; i < hi; ++i) {
+          int b = std::min(BINS - 1, std::max(0, (int)((prims[i].c[a] - cmin[a]) * k)));
+          grow(bb[b], prims[i].box);
+          bn[b]++;
+        }
+        double ra[BINS];
+        uint32_t rn[BINS];
+        Box acc = empty_box();
+        uint32_t n = 0;
+        for (int b = BINS - 1; b > 0; --b) { grow(acc, bb[b]); n += bn[b]; ra[b] = area(acc); rn[b] = n; }
+        acc = empty_box();
+        n = 0;
+        for (int b = 0; b < BINS - 1; ++b) {  // split after bin b
+          grow(acc, bb[b]);
+          n += bn[b];
+          if (n == 0 || rn[b + 1] == 0) continue;
+          const double cost = area(acc) * n + ra[b + 1] * rn[b + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; best_k = k; }
+        }
+      }
+    size_t mid;
+    if (best_axis >= 0) {
+      const int a = best_axis;
+      const float c0 = cmin[a];
+      auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [&](const Prim& p) {
+        return std::min(BINS - 1, std::max(0, (int)((p.c[a] - c0) * best_k))) <= best_bin;
+      });
+      mid = (size_t)(it - prims.begin());
+    } else {
+      mid = lo;
+    }
+    if (mid == lo || mid == hi) {  // coincident centroids (or the depth guard): median along the widest axis
+      int a = 0;
+      for (int k = 1; k < 3; ++k) if (cmax[k] - cmin[k] > cmax[a] - cmin[a]) a = k;
+      mid = lo + (hi - lo) / 2;
+      std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi, [a](const Prim& x, const Prim& y) { return x.c[a] < y.c[a]; });
+    }
+    const uint32_t ni = (uint32_t)nodes.size();
+    nodes.push_back(DNode{});
+    Box lb, rb;
+    const uint32_t lr = build(lo, mid, depth + 1, lb);
+    const uint32_t rr = build(mid, hi, depth + 1, rb);
+    DNode& dn = nodes[ni];
+    dn.lxmin = lb.v[0]; dn.lxmax = lb.v[1]; dn.lymin = lb.v[2]; dn.lymax = lb.v[3]; dn.lzmin = lb.v[4]; dn.lzmax = lb.v[5];
+    dn.rxmin = rb.v[0]; dn.rxmax = rb.v[1]; dn.rymin = rb.v[2]; dn.rymax = rb.v[3]; dn.rzmin = rb.v[4]; dn.rzmax = rb.v[5];
+    dn.left = lr; dn.right = rr; dn.pad0 = dn.pad1 = 0;
+    out_box = lb;
+    grow(out_box, rb);
+    return SOL_MAKE_REF(SOL_REF_NODE, ni);
+  }
+};
+
 template <typename T>
 int upload(const std::vector<T>& host, T** dev) {
   *dev = nullptr;
@@ -308,6 +471,7 @@ struct SolScene {
   int kernel_version = 0;          // 0 auto; SOL_KERNEL=v1|v2|v3 forces one (A/B comparisons)
   void* pool = nullptr; size_t pool_bytes = 0;  // path-slot pool of the wavefront kernels
   uint32_t pool_slots_override = 0;  // SOL_POOL_SLOTS (v2: slots per wave)
+  uint32_t switch_below = 0;         // SOL_SWITCH (v1, RenderParams::switch_below)
   uint32_t* queue = nullptr; size_t queue_slots = 0;  // v3 ray queue
   void* wf_ctr = nullptr; uint32_t* wf_ctr_host = nullptr;
   uint32_t wf_slots = 4u << 20;       // SOL_WF_SLOTS: pool size of the two-kernel wavefront
@@ -335,6 +499,8 @@ static int set_partition(SolScene* s, int rank, int world) {
   }
   return SOL_OK;
 }
+
+static int render_probe(SolScene* s);
 
 extern "C" {
 
@@ -505,12 +671,35 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
     }
   }
   // 8-wide tree of the world (a visit may push up to 7 children)
-  WideBuilder wb(tb.nodes);
-  uint32_t wroot = root_ref;
-  if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) wroot = wb.build(SOL_REF_INDEX(root_ref), 0);
-  const uint32_t world_stack = SOL_WORLD_BINARY ? world_depth : 7u * wb.max_depth;
-  const uint32_t tree_depth = world_stack + medium_depth + 2;
-  if (tree_depth > SOL_LDS_STACK + SOL_SPILL_STACK) return fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", tree_depth, SOL_LDS_STACK + SOL_SPILL_STACK);
+  // over the SAH rebuild of the world's tree (SOL_BVH=ref keeps the reference's topology: A/B runs, deep-tree tests)
+  const char* bvh_env = std::getenv("SOL_BVH");
+  SahBuilder sah;
+  uint32_t sah_root = SOL_MAKE_REF(SOL_REF_NONE, 0);
+  if (!(bvh_env && std::strcmp(bvh_env, "ref") == 0) && SOL_REF_KIND(root_ref) == SOL_REF_NODE && sah.collect(tb.nodes, root_ref)) {
+    Box b;
+    sah_root = sah.build(0, sah.prims.size(), 0, b);
+  }
+  WideBuilder wb_sah(sah.nodes), wb_ref(tb.nodes);
+  bool use_sah = false, calibrate = false;
+  uint32_t wroot = root_ref, wroot_ref = root_ref, wroot_sah = root_ref;
+  if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) wroot_ref = wb_ref.build(SOL_REF_INDEX(root_ref), 0);
+  auto depth_of = [&](const WideBuilder& w) { return (SOL_WORLD_BINARY ? world_depth : 7u * w.max_depth) + medium_depth + 2; };
+  const uint32_t stack_limit = SOL_LDS_STACK + SOL_SPILL_STACK;
+  if (SOL_REF_KIND(sah_root) == SOL_REF_NODE) {
+    wroot_sah = wb_sah.build(SOL_REF_INDEX(sah_root), 0);
+    const bool sah_ok = depth_of(wb_sah) <= stack_limit, ref_ok = depth_of(wb_ref) <= stack_limit;
+    if (sah_ok && (!ref_ok || (bvh_env && std::strcmp(bvh_env, "sah") == 0))) use_sah = true;
+    else if (sah_ok && !bvh_env) {
+      // Both usable: the surface-area estimate decides for now, a counted probe render on the device decides below (the
+      // estimate knows nothing of occlusion and visit order: it prefers the SAH tree for C2, which measures 10% slower).
+      use_sah = wb_sah.cost() < wb_ref.cost();
+      calibrate = !SOL_WORLD_BINARY;
+    }
+  }
+  wroot = use_sah ? wroot_sah : wroot_ref;
+  WideBuilder* wb = use_sah ? &wb_sah : &wb_ref;
+  uint32_t tree_depth = depth_of(*wb);
+  if (tree_depth > stack_limit) return fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", tree_depth, stack_limit);
 
   // ---- lights ----
   std::vector<uint32_t> lights(d->lights, d->lights + d->n_lights);
@@ -534,7 +723,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   s->stream = s->own_stream;
   int rc;
-  if ((rc = upload(tb.nodes, &s->nodes)) || (rc = upload(wb.out, &s->wides)) || (rc = upload(tris, &s->tris)) || (rc = upload(tshade, &s->tri_shade)) ||
+  if ((rc = upload(tb.nodes, &s->nodes)) || (rc = upload(wb->out, &s->wides)) || (rc = upload(tris, &s->tris)) || (rc = upload(tshade, &s->tri_shade)) ||
       (rc = upload(quads, &s->quads)) || (rc = upload(spheres, &s->spheres)) || (rc = upload(mediums, &s->mediums)) ||
       (rc = upload(mats, &s->mats)) || (rc = upload(texs, &s->texs)) || (rc = upload(lights, &s->lights)))
     return rc;
@@ -567,6 +756,11 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
     if (kv[0] == 'v') kv++;
     s->kernel_version = (kv[0] >= '1' && kv[0] <= '3') ? kv[0] - '0' : 0;
   }
+  // v1's search/shade switch (RenderParams::switch_below), measured on MI355X at 1080p: 16/64 is the best common setting
+  // for worlds with a real tree (C3 127 -> 107 ms, C2 100 -> 78 ms per 64 spp); a world of a few wide nodes (the Cornell box:
+  // 1.3 node visits per ray) has no search imbalance to hide, and shading finished lanes early only dilutes the shading.
+  s->switch_below = wb->out.size() > 8 ? 16u : 0u;
+  if (const char* ps = std::getenv("SOL_SWITCH")) s->switch_below = (uint32_t)std::min(64, std::max(0, std::atoi(ps)));
   if (const char* ps = std::getenv("SOL_POOL_SLOTS")) s->pool_slots_override = (uint32_t)std::atoi(ps);
   if (const char* ps = std::getenv("SOL_WF_SLOTS")) s->wf_slots = std::max(4096, std::atoi(ps));
   if (const char* ps = std::getenv("SOL_WF_MIN_ITEMS")) s->wf_min_items = (uint32_t)std::max(0, std::atoi(ps));
@@ -575,6 +769,34 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   s->blocks_x = (d->width + SOL_TILE - 1) / SOL_TILE;
   s->blocks_y = (d->height + SOL_TILE - 1) / SOL_TILE;
   if ((rc = set_partition(s, 0, 1))) return rc;
+  if (calibrate) {
+    // Probe both world trees with a counted render of 16 samples per pixel over ~256 pixel blocks spread across the image and
+    // keep the one with less search work (a wide-node visit weighs ~2.5 primitive tests, by instruction count). Images do
+    // not depend on the tree, the counters are deterministic, so is the choice.
+    DWide* other = nullptr;
+    WideBuilder* wo = use_sah ? &wb_ref : &wb_sah;
+    if ((rc = upload(wo->out, &other))) return rc;
+    struct Cand { DWide* w; uint32_t root; uint32_t depth; WideBuilder* b; double cost; } cand[2] = {
+        {s->wides, wroot, tree_depth, wb, 0.}, {other, use_sah ? wroot_ref : wroot_sah, depth_of(*wo), wo, 0.}};
+    const uint32_t nb = s->blocks_x * s->blocks_y;
+    rc = set_partition(s, 0, (int)std::max(1u, nb / 256u));
+    for (int k = 0; k < 2 && !rc; ++k) {
+      S.wides = cand[k].w; S.wroot = cand[k].root; s->tree_depth = cand[k].depth;
+      if (!(rc = sol_clear(s)) && !(rc = render_probe(s)))
+        cand[k].cost = 2.5 * (double)s->stats.node_visits + (double)(s->stats.sphere_tests + s->stats.quad_tests + s->stats.triangle_tests);
+    }
+    const int pick = (!rc && cand[1].cost < cand[0].cost) ? 1 : 0;
+    if (std::getenv("SOL_VERBOSE"))
+      std::fprintf(stderr, "[solstrale] world tree probe: %s cost %.4g, %s cost %.4g -> %s\n", use_sah ? "SAH" : "reference", cand[0].cost,
+                   use_sah ? "reference" : "SAH", cand[1].cost, (pick == 0) == use_sah ? "SAH" : "reference");
+    hipFree(cand[1 - pick].w);
+    s->wides = cand[pick].w;
+    S.wides = s->wides; S.wroot = cand[pick].root; s->tree_depth = cand[pick].depth;
+    if (!std::getenv("SOL_SWITCH")) s->switch_below = cand[pick].b->out.size() > 8 ? 16u : 0u;
+    s->stats = SolStats{};
+    if (rc || (rc = set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
   cleanup.keep = true;
   *out = s;
   return SOL_OK;
@@ -631,6 +853,7 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
   if (items > 0xFFFF0000ull) return fail(SOL_EINVAL, "too many work items in one call (%llu): split the sample range", (unsigned long long)items);
   P.n_items = (uint32_t)items;
   if (P.n_items == 0) return SOL_OK;
+  P.switch_below = s->switch_below;
   // kernel choice: 0 = auto (two-kernel wavefront for large jobs, one-path-per-lane kernel for small ones)
   int version = s->kernel_version;
   // Measured on MI355X (C3, 128 spp): v1 997, v2 905, v3 684 Msamples/s - the wavefront variants raise the traversal's lane
@@ -751,6 +974,7 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
   return SOL_OK;
 }
 
+static int render_probe(SolScene* s) { return render_impl(s, 0, SOL_CHUNK, 0x50B3ull, true); }
 int sol_render(SolScene* s, uint32_t first, uint32_t n, uint64_t seed) { return render_impl(s, first, n, seed, false); }
 int sol_render_counted(SolScene* s, uint32_t first, uint32_t n, uint64_t seed) { return render_impl(s, first, n, seed, true); }
 

@@ -27,7 +27,7 @@
 // v1: one path per lane
 // ---------------------------------------------------------------------------------------------------------------------------
 template <bool COUNT, bool MEDIUM>
-__global__ void __launch_bounds__(SOL_WG)
+__global__ void __launch_bounds__(SOL_WG, 4)  // 4 waves per SIMD: the 32 KiB LDS stack allows 5 workgroups per CU, 128 VGPRs 4
 sol_render_kernel(const DevScene S, const RenderParams P, float* __restrict__ acc, float* __restrict__ partial,
                   uint32_t* __restrict__ work_counter, uint32_t* __restrict__ spill, DevCounters* __restrict__ dcnt) {
   __shared__ uint32_t lds_stack[SOL_LDS_STACK * SOL_WG];
@@ -42,48 +42,66 @@ sol_render_kernel(const DevScene S, const RenderParams P, float* __restrict__ ac
   Counters cnt = {};
   const float inf = __builtin_huge_valf();
 
-  bool have_item = false, alive = false;
+  bool have_item = false, alive = false, in_flight = false;
   Item it = {0, 0, 0, 0};
   uint32_t s = 0, s_end = 0;
   f3 sum = mk3(0.f, 0.f, 0.f);
   Path p = {};
+  Trav t;
+  t.cur = REF_DONE;
 
   for (;;) {
-    // ---- work fetch: one atomic per wave, lanes take consecutive items (an aligned wave = one 8x8 pixel block) ----
-    if (!have_item) {
-      const unsigned long long need = __ballot(1);
-      const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(work_counter, (uint32_t)__popcll(need));
-      base = __shfl(base, (int)leader);
-      const uint32_t item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-      if (item >= P.n_items) break;  // no work left for this lane
-      if (!decode_item(S, P, item, it)) continue;
-      s = P.first_sample + it.chunk * SOL_CHUNK;
-      s_end = min(s + SOL_CHUNK, P.first_sample + P.n_samples);
-      sum = mk3(0.f, 0.f, 0.f);
-      have_item = true;
-      alive = false;
-    }
-    if (!alive) {
-      phase_tick<COUNT>(cnt, 2);
-      generate_path<COUNT>(S, P.seed_lo, P.seed_hi, it.px, it.py, s, p, cnt);
-      alive = true;
-    }
-    // ---- intersect: world.hit(ray, RAY_INTERVAL) (src/renderer/mod.rs:165) ----
-    Hit h;
-    closest_hit<COUNT, MEDIUM, SOL_WORLD_BINARY>(S, p.o, p.d, RAY_MIN_F, inf, SOL_WORLD_ROOT(S), S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, h, st, 0,
-                               p.rng, p.depth, cnt);
-    if (COUNT) cnt.rays++;
-    f3 c;
-    if (shade_vertex<COUNT>(S, p, h, c, cnt)) {
-      sum = sum + c;  // add_row_data (src/renderer/mod.rs:361-365): sums, not means
-      alive = false;
-      s++;
-      if (s == s_end) {
-        write_chunk(P, acc, partial, it.slot, it.chunk, sum);
-        have_item = false;
+    // ---- lanes whose search is over: shade the vertex, then start the next ray of the path / sample / item ----
+    if (t.cur == REF_DONE) {
+      if (in_flight) {
+        in_flight = false;
+        if (COUNT) cnt.rays++;
+        p.o = t.o; p.d = t.d;  // (the ray lives in the search state while it is traced)
+        f3 c;
+        if (shade_vertex<COUNT>(S, p, t.h, c, cnt)) {
+          sum = sum + c;  // add_row_data (src/renderer/mod.rs:361-365): sums, not means
+          alive = false;
+          s++;
+          if (s == s_end) {
+            write_chunk(P, acc, partial, it.slot, it.chunk, sum);
+            have_item = false;
+          }
+        }
       }
+      // work fetch: one atomic per wave, lanes take consecutive items (an aligned wave = one 8x8 pixel block)
+      if (!have_item) {
+        const unsigned long long need = __ballot(1);
+        const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(work_counter, (uint32_t)__popcll(need));
+        base = __shfl(base, (int)leader);
+        const uint32_t item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+        if (item >= P.n_items) break;  // no work left for this lane
+        if (!decode_item(S, P, item, it)) continue;
+        s = P.first_sample + it.chunk * SOL_CHUNK;
+        s_end = min(s + SOL_CHUNK, P.first_sample + P.n_samples);
+        sum = mk3(0.f, 0.f, 0.f);
+        have_item = true;
+        alive = false;
+      }
+      if (!alive) {
+        phase_tick<COUNT>(cnt, 2);
+        generate_path<COUNT>(S, P.seed_lo, P.seed_hi, it.px, it.py, s, p, cnt);
+        alive = true;
+      }
+      // world.hit(ray, RAY_INTERVAL) (src/renderer/mod.rs:165)
+      trav_begin(t, p.o, p.d, RAY_MIN_F, inf, SOL_WORLD_ROOT(S), S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
+      in_flight = true;
+    }
+    // ---- search: one step per turn for every lane that has one. The wave leaves for the shading block when too few of
+    // its lanes are still searching while others wait (P.switch_below 64ths of the live lanes; 0: when none is searching).
+    for (;;) {
+      const bool act = t.cur != REF_DONE;
+      const unsigned long long am = __ballot(act);
+      if (am == 0ull) break;
+      const unsigned long long live = __ballot(1);
+      if (am != live && (uint32_t)__popcll(am) * 64u < P.switch_below * (uint32_t)__popcll(live)) break;
+      if (act) trav_step<COUNT, MEDIUM, SOL_WORLD_BINARY>(S, t, st, p.rng, p.depth, cnt);
     }
   }
   if (COUNT) flush_counters(cnt, dcnt);

@@ -146,12 +146,19 @@ DEV bool better(float t, uint32_t dfs, const Hit& h) {
   return t < h.t || (t == h.t && (SOL_REF_KIND(h.ref) == SOL_REF_NONE || dfs > h.dfs));
 }
 
+// Visit order of the 8-wide tree: kWideFar[octant] = {slots 0-3, slots 4-7}, byte i = mask of the slots j that come after
+// slot i for a ray of that direction octant, i.e. (j ^ octant) > (i ^ octant).
+static __device__ const uint2 kWideFar[8] = {
+    {0xF0F8FCFEu, 0x0080C0E0u}, {0xF4F0FDFCu, 0x4000D0C0u}, {0xF3FBF0F2u, 0x30B00020u}, {0xF7F3F1F0u, 0x70301000u},
+    {0x00080C0Eu, 0x0F8FCFEFu}, {0x04000D0Cu, 0x4F0FDFCFu}, {0x030B0002u, 0x3FBF0F2Fu}, {0x07030100u, 0x7F3F1F0Fu}};
+
 // State of one closest-hit search.
 struct Trav {
   f3 o, d, inv;
   float tmin;
   uint32_t cur;  // reference being visited, REF_DONE when the search is over
   int sp, sp_base;
+  uint2 far;     // kWideFar[ray octant] (8-wide searches only)
   Hit h;
 };
 
@@ -167,6 +174,7 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
   t.h.u = t.h.v = 0.0f;
   t.sp = t.sp_base = sp_base;
   t.cur = root;
+  t.far = make_uint2(0u, 0u);
   // A ray with a NaN in its origin or direction cannot hit anything: every primitive test ends in a comparison with NaN,
   // which is false (the reference returns None the same way, after visiting every box - Aabb::hit ignores NaN). Such rays
   // occur a few times per 10^8 samples; without this exit one lane walks the whole tree and tests every primitive.
@@ -176,6 +184,8 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
     if (!slab(bxmin, bxmax, bymin, bymax, bzmin, bzmax, o, t.inv, __builtin_signbitf(t.inv.x), __builtin_signbitf(t.inv.y),
               __builtin_signbitf(t.inv.z), te))
       t.cur = REF_DONE;
+    if (SOL_REF_KIND(root) == SOL_REF_WIDE)
+      t.far = kWideFar[(__builtin_signbitf(t.inv.x) ? 4u : 0u) | (__builtin_signbitf(t.inv.y) ? 2u : 0u) | (__builtin_signbitf(t.inv.z) ? 1u : 0u)];
   }
 }
 
@@ -195,18 +205,27 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
     const float tny = fmaf((float)(((nyw) >> (8 * ((i) & 3))) & 0xFFu), by, ay), tfy = fmaf((float)(((fyw) >> (8 * ((i) & 3))) & 0xFFu), by, ay); \
     const float tnz = fmaf((float)(((nzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az), tfz = fmaf((float)(((fzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az); \
     const float te = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));                                                         \
-    const float tx = fminf(fminf(tfx, tfy), tfz);                                                                       \
-    const bool hit = SOL_REF_KIND(refv) != SOL_REF_NONE && te <= tx && te <= cull_t;                                    \
-    hits |= hit ? (1u << (i)) : 0u;                                                                                     \
-    hm |= hit ? (1u << ((i) ^ oct)) : 0u;                                                                               \
+    const float tx = fminf(fminf(tfx, tfy), fminf(tfz, cull_t));                                                        \
+    hits |= (te <= tx) ? (1u << (i)) : 0u; /* an empty slot has an inverted box; at worst it yields a NONE ref (no-op) */ \
   }
-// Second pass: the nearest hit child (lowest order index) becomes the current reference, the others go on the stack so
-// that the nearest of them is on top (position = number of hit children that are farther).
-#define SOL_WIDE_PLACE(i, refv)                                                                  \
-  if (hits & (1u << (i))) {                                                                      \
-    const uint32_t k = (uint32_t)(i) ^ oct;                                                      \
-    if (k == first) t.cur = (refv);                                                              \
-    else stack_store(st, t.sp + (int)__popc(hm >> (k + 1u)), (refv));                           \
+// Second pass. Children are visited in order of k = slot ^ octant (slots are octants of the node's split planes, so this
+// is front to back along the ray's direction signs). The nearest hit child becomes the current reference, the others go
+// on the stack with the nearest of them on top: level = sp + (number of hit children that are farther). "Farther than
+// slot i" is a fixed slot set per ray octant (kWideFar, one byte per slot), so a level costs and + popcount.
+// Fast form (whole node fits in the LDS part of the stack): branch-free - a child that was not hit is stored to a scratch
+// level above everything live, the nearest child is stored too (at sp + n - 1, the level the stack does not keep).
+#define SOL_WIDE_PLACE_FAST(i, refv, farw)                                                                   \
+  {                                                                                                          \
+    const uint32_t pos = __popc(hits & (((farw) >> (8 * ((i) & 3))) & 0xFFu));                                \
+    const uint32_t lvl = (hits & (1u << (i))) ? pos : 8u;                                                     \
+    base[lvl * SOL_WG] = (refv);                                                                             \
+    nearest = (lvl == n_hit - 1u) ? (refv) : nearest;                                                        \
+  }
+#define SOL_WIDE_PLACE(i, refv, farw)                                                                        \
+  if (hits & (1u << (i))) {                                                                                  \
+    const uint32_t pos = __popc(hits & (((farw) >> (8 * ((i) & 3))) & 0xFFu));                                \
+    if (pos == n_hit - 1u) t.cur = (refv);                                                                   \
+    else stack_store(st, t.sp + (int)pos, (refv));                                                           \
   }
 
 // One step: visits the node or primitive t.cur, then moves to the next reference (near child, or popped from the stack).
@@ -220,7 +239,6 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
   phase_tick<COUNT>(cnt, 0);
   if (!BINARY && kind == SOL_REF_WIDE) {
     const bool sx = __builtin_signbitf(t.inv.x), sy = __builtin_signbitf(t.inv.y), sz = __builtin_signbitf(t.inv.z);
-    const uint32_t oct = (sx ? 4u : 0u) | (sy ? 2u : 0u) | (sz ? 1u : 0u);
     const float4* wp = reinterpret_cast<const float4*>(S.wides + idx);
     const float4 h = wp[0];
     const uint4 qa = *reinterpret_cast<const uint4*>(wp + 1), qb = *reinterpret_cast<const uint4*>(wp + 2);
@@ -235,7 +253,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
 #else
     const float cull_t = t.h.t;  // t >= tmin > 0 in a world search
 #endif
-    uint32_t hits = 0u, hm = 0u;
+    uint32_t hits = 0u;
     // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
     // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
     // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
@@ -257,11 +275,24 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, rb.y)
     SOL_WIDE_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, rb.z)
     SOL_WIDE_CHILD(7, nx1, ny1, nz1, fx1, fy1, fz1, rb.w)
-    if (hm != 0u) {
-      const uint32_t first = (uint32_t)__ffs((int)hm) - 1u;
-      SOL_WIDE_PLACE(0, ra.x) SOL_WIDE_PLACE(1, ra.y) SOL_WIDE_PLACE(2, ra.z) SOL_WIDE_PLACE(3, ra.w)
-      SOL_WIDE_PLACE(4, rb.x) SOL_WIDE_PLACE(5, rb.y) SOL_WIDE_PLACE(6, rb.z) SOL_WIDE_PLACE(7, rb.w)
-      t.sp += (int)__popc(hm) - 1;
+    // keeps the loads of the references with the loads of the boxes (the compiler would sink them behind the branch, a
+    // second dependent memory round trip per node)
+    asm volatile("" ::"v"(ra.x), "v"(ra.y), "v"(ra.z), "v"(ra.w), "v"(rb.x), "v"(rb.y), "v"(rb.z), "v"(rb.w));
+    if (hits != 0u) {
+      const uint32_t n_hit = __popc(hits);
+      if (t.sp + 9 <= st.depth) {
+        uint32_t* base = st.lds + t.sp * SOL_WG;
+        uint32_t nearest = 0u;
+        SOL_WIDE_PLACE_FAST(0, ra.x, t.far.x) SOL_WIDE_PLACE_FAST(1, ra.y, t.far.x) SOL_WIDE_PLACE_FAST(2, ra.z, t.far.x)
+        SOL_WIDE_PLACE_FAST(3, ra.w, t.far.x) SOL_WIDE_PLACE_FAST(4, rb.x, t.far.y) SOL_WIDE_PLACE_FAST(5, rb.y, t.far.y)
+        SOL_WIDE_PLACE_FAST(6, rb.z, t.far.y) SOL_WIDE_PLACE_FAST(7, rb.w, t.far.y)
+        t.cur = nearest;
+      } else {  // the node may reach the spill area: generic stores
+        SOL_WIDE_PLACE(0, ra.x, t.far.x) SOL_WIDE_PLACE(1, ra.y, t.far.x) SOL_WIDE_PLACE(2, ra.z, t.far.x)
+        SOL_WIDE_PLACE(3, ra.w, t.far.x) SOL_WIDE_PLACE(4, rb.x, t.far.y) SOL_WIDE_PLACE(5, rb.y, t.far.y)
+        SOL_WIDE_PLACE(6, rb.z, t.far.y) SOL_WIDE_PLACE(7, rb.w, t.far.y)
+      }
+      t.sp += (int)n_hit - 1;
       if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
       return;
     }

@@ -147,6 +147,8 @@ struct RenderParams {
   uint32_t n_items;          // n_chunks * n_local_blocks * 64
   uint32_t total_threads;    // grid * SOL_WG (spill stack stride)
   uint32_t pool_slots;       // pool kernel: path slots per wave (multiple of 64, <= SOL_POOL_MAX)
+  uint32_t switch_below;     // v1: a wave leaves the search loop for shading once fewer than this many of its live lanes
+                             // (in 64ths) are still searching and some lane waits; 0 = search until every lane is done
 };
 
 struct DevCounters {

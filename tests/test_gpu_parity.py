@@ -193,9 +193,12 @@ def test_max_depth_zero_and_one():
         assert_parity(scenes.cornell_box(RenderConfig(64, 64, 8, PathTracingShader(md))), 8)
 
 
-def test_deep_tree_uses_the_spill_stack():
+@pytest.mark.parametrize("bvh", ["ref", "sah"])
+def test_deep_tree_uses_the_spill_stack(bvh, monkeypatch):
     """A BVH nested 48 levels deep (Bvh::new([sphere, Bvh::new([sphere, ...])]), each nested Bvh inlined as a node) is deeper
-    than the 32-entry LDS stack: the overflow goes to the global spill area."""
+    than the 32-entry LDS stack: the overflow goes to the global spill area. SOL_BVH=ref makes the device walk the reference's
+    own topology (its default is a SAH rebuild of the world, which re-balances this chain)."""
+    monkeypatch.setenv("SOL_BVH", bvh)
     b = SceneBuilder()
     m = b.Lambertian(b.SolidColor(.8, .8, .8))
     ids = [b.Sphere((float(x), 0.3 * (x % 3), 0.), 0.45, m) for x in range(50)]
@@ -213,7 +216,8 @@ def test_deep_tree_uses_the_spill_stack():
     ref, _ = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F32)
     assert pu.compare(img, ref, 4)["bad_pixels"] == 0
     assert st["samples"] == 64 * 64 * 4 and st["rays"] >= st["samples"]
-    assert st["max_stack"] > 32, st  # the spill area was really used
+    if bvh == "ref":
+        assert st["max_stack"] > 32, st  # the spill area was really used
 
 
 def test_errors_are_codes_not_crashes():
