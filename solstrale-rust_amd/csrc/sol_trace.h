@@ -224,7 +224,7 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
 #define SOL_WIDE_PLACE(i, refv, farw)                                                                        \
   if (hits & (1u << (i))) {                                                                                  \
     const uint32_t pos = __popc(hits & (((farw) >> (8 * ((i) & 3))) & 0xFFu));                                \
-    if (pos == n_hit - 1u) t.cur = (refv);                                                                   \
+    if (pos == n_hit - 1u) cur = (refv);                                                                     \
     else stack_store(st, t.sp + (int)pos, (refv));                                                           \
   }
 
@@ -233,11 +233,14 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
 // search interval includes negative t) or the 8-wide DWide tree (the world).
 template <bool COUNT, bool MEDIUM, bool BINARY>
 DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
-  const uint32_t cur = t.cur;
-  const uint32_t kind = SOL_REF_KIND(cur);
-  const uint32_t idx = SOL_REF_INDEX(cur);
+  uint32_t cur = t.cur;
+  uint32_t kind = SOL_REF_KIND(cur);
   phase_tick<COUNT>(cnt, 0);
+  // Part 1: an inner node, if the lane is at one; its nearest hit child (or, when no child is hit, the top of the stack)
+  // becomes `cur`. Part 2: a primitive, if `cur` is one now. A lane so advances by up to two visits per step, while a wave
+  // whose lanes are spread over nodes and primitives pays for both parts on every step anyway.
   if (!BINARY && kind == SOL_REF_WIDE) {
+    const uint32_t idx = SOL_REF_INDEX(cur);
     const bool sx = __builtin_signbitf(t.inv.x), sy = __builtin_signbitf(t.inv.y), sz = __builtin_signbitf(t.inv.z);
     const float4* wp = reinterpret_cast<const float4*>(S.wides + idx);
     const float4 h = wp[0];
@@ -286,7 +289,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
         SOL_WIDE_PLACE_FAST(0, ra.x, t.far.x) SOL_WIDE_PLACE_FAST(1, ra.y, t.far.x) SOL_WIDE_PLACE_FAST(2, ra.z, t.far.x)
         SOL_WIDE_PLACE_FAST(3, ra.w, t.far.x) SOL_WIDE_PLACE_FAST(4, rb.x, t.far.y) SOL_WIDE_PLACE_FAST(5, rb.y, t.far.y)
         SOL_WIDE_PLACE_FAST(6, rb.z, t.far.y) SOL_WIDE_PLACE_FAST(7, rb.w, t.far.y)
-        t.cur = nearest;
+        cur = nearest;
       } else {  // the node may reach the spill area: generic stores
         SOL_WIDE_PLACE(0, ra.x, t.far.x) SOL_WIDE_PLACE(1, ra.y, t.far.x) SOL_WIDE_PLACE(2, ra.z, t.far.x)
         SOL_WIDE_PLACE(3, ra.w, t.far.x) SOL_WIDE_PLACE(4, rb.x, t.far.y) SOL_WIDE_PLACE(5, rb.y, t.far.y)
@@ -294,9 +297,12 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       }
       t.sp += (int)n_hit - 1;
       if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
-      return;
+    } else {
+      cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
     }
+    kind = SOL_REF_KIND(cur);
   } else if (BINARY && kind == SOL_REF_NODE) {
+    const uint32_t idx = SOL_REF_INDEX(cur);
     const bool sx = __builtin_signbitf(t.inv.x), sy = __builtin_signbitf(t.inv.y), sz = __builtin_signbitf(t.inv.z);
     const float4* np = reinterpret_cast<const float4*>(S.nodes + idx);
     const float4 a = np[0], b = np[1], c = np[2];
@@ -324,12 +330,19 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       const bool lfirst = tl <= tr;
       stack_push(st, t.sp, lfirst ? r.y : r.x);
       if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
-      t.cur = lfirst ? r.x : r.y;
-      return;
+      cur = lfirst ? r.x : r.y;
+    } else if (hl) {
+      cur = r.x;
+    } else if (hr) {
+      cur = r.y;
+    } else {
+      cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
     }
-    if (hl) { t.cur = r.x; return; }
-    if (hr) { t.cur = r.y; return; }
-  } else if (kind == SOL_REF_TRIANGLE) {
+    kind = SOL_REF_KIND(cur);
+  }
+  if (cur == REF_DONE || kind == (BINARY ? SOL_REF_NODE : SOL_REF_WIDE)) { t.cur = cur; return; }
+  const uint32_t idx = SOL_REF_INDEX(cur);
+  if (kind == SOL_REF_TRIANGLE) {
     const float4* tp = reinterpret_cast<const float4*>(S.tris + idx);
     const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
     DTri T;
