@@ -1,0 +1,56 @@
+"""Folds the rocprofv3 --pmc passes of tests/profile_round.sh into one JSON summary (not a pytest).
+Usage: python tests/pmc_summary.py gpurun_out/<tag>_pmc <kernel-name-substring> <samples-in-the-launch> > profiles/<tag>_pmc_summary.json
+
+Counters are summed over every dispatch whose kernel name contains the substring (bench.py --steps 1 --warmup 0 launches
+the uncounted render kernel exactly once). Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM):
+FETCH_SIZE / WRITE_SIZE are KiB of L2<->fabric requests (Infinity-Cache hits included); on gfx950 FETCH_SIZE tallies a
+128-B request as 64 B, so reads are doubled for the "corrected" figure (an upper bound for narrow accesses)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    root, kname, samples = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    counters, dur_ns = {}, []
+    for f in sorted(glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv"))):
+        seen = set()
+        for row in csv.DictReader(open(f)):
+            if kname not in row["Kernel_Name"]:
+                continue
+            counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            if row["Dispatch_Id"] not in seen:
+                seen.add(row["Dispatch_Id"])
+                dur_ns.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    c = counters
+    g = lambda k: c.get(k, float("nan"))
+    n_simd = 256 * 4
+    kernel_ms = sum(dur_ns) / max(1, len(dur_ns)) / 1e6
+    d = {
+        "kernel_ms_under_pmc (mean of the passes)": round(kernel_ms, 2),
+        "valu_insts_per_sample": g("SQ_INSTS_VALU") / samples,
+        "salu_insts_per_sample": g("SQ_INSTS_SALU") / samples,
+        "vmem_read_insts_per_sample": g("SQ_INSTS_VMEM_RD") / samples,
+        "lds_insts_per_sample": g("SQ_INSTS_LDS") / samples,
+        # SQ_* cycle counters count quad-cycles (guide: 'tick vs SQ PMC units')
+        "valu_lane_utilization (THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64))": g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64.0),
+        "simd_valu_busy_frac (ACTIVE_INST_VALU*4 / (SIMDs * kernel cycles @2.4GHz))": g("SQ_ACTIVE_INST_VALU") * 4.0 / (n_simd * kernel_ms * 1e-3 * 2.4e9),
+        "wave_cycles_waiting_frac (WAIT_ANY / WAVE_CYCLES)": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"),
+        "wave_cycles_issue_stall_frac (WAIT_INST_ANY / WAVE_CYCLES)": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
+        "mean_waves_per_simd (WAVE_CYCLES / BUSY_CYCLES ... per SE-normalised)": g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CYCLES"),
+        "l1_hit_rate (1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)": 1.0 - g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum"),
+        "l2_hit_rate (TCC_HIT / (TCC_HIT + TCC_MISS))": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")),
+        "ta_busy_percent_avr": g("TA_BUSY_avr"),
+        "fabric_read_bytes_uncorrected (FETCH_SIZE KiB * 1024)": g("FETCH_SIZE") * 1024.0,
+        "fabric_read_bytes_corrected_x2": g("FETCH_SIZE") * 2048.0,
+        "fabric_write_bytes (WRITE_SIZE KiB * 1024)": g("WRITE_SIZE") * 1024.0,
+        "fabric_bytes_per_sample_corrected": (g("FETCH_SIZE") * 2048.0 + g("WRITE_SIZE") * 1024.0) / samples,
+    }
+    json.dump({"kernel": kname, "samples_in_launch": samples, "counters": counters, "derived": d}, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
