@@ -236,6 +236,25 @@ int sol_unpermute(SolScene* scene, const void* gathered_dev, int world, void* im
  * `rgb8_host` receives W*H*3 bytes. */
 int sol_tonemap_rgb8(SolScene* scene, const void* image_dev, uint32_t num_samples, uint8_t* rgb8_host);
 
+/* Un-permutes this scene's own accumulators into its internal row-major image buffer (W*H*3 floats, row 0 = top, device
+ * memory owned by the scene, valid until the next sol_read / sol_resolve_image) and returns its device pointer: the input
+ * of the device-side post-processors when no gather is involved (single GPU). Asynchronous on the scene's stream. */
+int sol_resolve_image(SolScene* scene, void** image_dev);
+
+/* Device-side BloomPostProcessor (src/post/bloom.rs:76-150), f64 arithmetic in the reference's summation order on the
+ * fp32 sums of `image_dev` (W*H*3 floats, row-major, device). `threshold` and `max_intensity` are per-sample values
+ * (BloomPostProcessor::new's defaults: |(1,1,1)| and f64::MAX); kernel_size_fraction outside [0, 0.5] is SOL_EINVAL with
+ * the reference's message.
+ *   sol_bloom       = intermediate_post_process: image_dev <- pixel + blurred bright pixels, rounded to fp32, in place;
+ *   sol_bloom_rgb8  = post_process: the same sums carried in f64 through to_rgb_color into rgb8_host (W*H*3 bytes).
+ *  */
+int sol_bloom(SolScene* scene, void* image_dev, uint32_t num_samples, double kernel_size_fraction, double threshold,
+              double max_intensity);
+int sol_bloom_rgb8(SolScene* scene, const void* image_dev, uint32_t num_samples, double kernel_size_fraction, double threshold,
+                   double max_intensity, uint8_t* rgb8_host);
+/* create_gaussian_blur_weights (src/util/gaussian.rs:11-25), the weights sol_bloom uses; host-only, for known-answer tests. */
+int sol_gaussian_blur_weights(uint32_t kernel_size, double std_dev, double* out);
+
 int sol_stats(const SolScene* scene, SolStats* out);
 
 /* Diagnostic: traces the single path (pixel x, y counted from the image top; sample index) and writes 12 floats per ray

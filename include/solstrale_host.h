@@ -74,6 +74,12 @@ uint32_t solh_tree_depth(const SolhBuilder* b);
  * callback per sample index (image pointer non-NULL when the strategy produced one; RGB8, row 0 top),
  * abort callback polled between batches (may be NULL). strategy: 0 EverySample, 1 Interval(seconds),
  * 2 OnlyFinal. Returns 0, or negative with solh_last_error() = the reference's error string. */
+/* RenderConfig::post_processors (src/renderer/mod.rs:35) for the following solh_ray_trace calls: kinds[i] 0 = NopPostProcessor,
+ * 1 = BloomPostProcessor with params[3i..3i+2] = kernel_size_fraction, threshold, max_intensity (NaN = None); n = 0: no image
+ * is produced. The default is one NopPostProcessor. Errors carry the reference's strings
+ * ("kernel_size_fraction must be between 0 and 0.5"). */
+int solh_set_post_processors(SolhBuilder* b, int n, const int* kinds, const double* params);
+
 typedef void (*solh_progress_fn)(void* user, double progress, double fps, double eta_seconds,
                                  const uint8_t* image_rgb8, uint32_t width, uint32_t height);
 typedef int (*solh_abort_fn)(void* user);

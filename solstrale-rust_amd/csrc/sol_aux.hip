@@ -48,6 +48,79 @@ __global__ void __launch_bounds__(256) sol_tonemap_kernel(const float* __restric
   }
 }
 
+// ---- BloomPostProcessor (src/post/bloom.rs:76-150) in f64, the reference's arithmetic and summation order ----------------
+// Pixel sums are the device's fp32 sums promoted to double. Buffers `a`, `b` hold W*H*3 doubles.
+// 1. bright pass (bloom.rs:93-106): keep a pixel whose length reaches the threshold, scaled back to max_intensity.
+__global__ void __launch_bounds__(256) sol_bloom_bright_kernel(const float* __restrict__ image, double* __restrict__ out, uint32_t npix,
+                                                               double threshold, double max_intensity) {
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+    const double x = (double)image[(size_t)p * 3], y = (double)image[(size_t)p * 3 + 1], z = (double)image[(size_t)p * 3 + 2];
+    const double len = sqrt(x * x + y * y + z * z);  // Vec3::length (vec3.rs:282-295)
+    double ox = 0.0, oy = 0.0, oz = 0.0;
+    if (len >= threshold) {
+      if (len > max_intensity) {  // p.unit() * max_intensity
+        ox = (x / len) * max_intensity; oy = (y / len) * max_intensity; oz = (z / len) * max_intensity;
+      } else {
+        ox = x; oy = y; oz = z;
+      }
+    }
+    out[(size_t)p * 3] = ox; out[(size_t)p * 3 + 1] = oy; out[(size_t)p * 3 + 2] = oz;
+  }
+}
+// 2./3. separable blur (bloom.rs:108-142): col += get_pixel_safe(..) * weights[i] for i = 0..k-1 in this order, coordinates
+// clamped to the image (bloom.rs:153-158). VERTICAL selects the axis. Consecutive lanes read consecutive pixels for every tap
+// (coalesced 24-B records); the k-fold re-reads are served by L1/L2.
+template <bool VERTICAL>
+__global__ void __launch_bounds__(256) sol_bloom_blur_kernel(const double* __restrict__ in, double* __restrict__ out, uint32_t width,
+                                                             uint32_t height, const double* __restrict__ weights, uint32_t k) {
+  const int half = (int)(k / 2);
+  const uint32_t npix = width * height;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+    const int x = (int)(p % width), y = (int)(p / width);
+    double cx = 0.0, cy = 0.0, cz = 0.0;
+    for (uint32_t i = 0; i < k; ++i) {
+      int sx = x, sy = y;
+      if (VERTICAL) sy = min(max(y + (int)i - half, 0), (int)height - 1);
+      else sx = min(max(x + (int)i - half, 0), (int)width - 1);
+      const double* s = in + ((size_t)sy * width + sx) * 3;
+      const double w = weights[i];
+      cx = cx + s[0] * w; cy = cy + s[1] * w; cz = cz + s[2] * w;
+    }
+    out[(size_t)p * 3] = cx; out[(size_t)p * 3 + 1] = cy; out[(size_t)p * 3 + 2] = cz;
+  }
+}
+// 4. pixel + blurred (bloom.rs:144-148); then either back to the fp32 image (intermediate_post_process, rounded to fp32:
+// the device keeps fp32 sums) or straight through to_rgb_color in f64 (post_process).
+__global__ void __launch_bounds__(256) sol_bloom_finish_kernel(float* __restrict__ image, const double* __restrict__ blurred,
+                                                               uint8_t* __restrict__ rgb, uint32_t n, uint32_t spp) {
+  const double scale = 1.0 / (double)spp;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double sum = (double)image[i] + blurred[i];
+    if (rgb) {
+      double v = sqrt(scale * sum);
+      if (v < -0.999) v = -0.999;
+      if (v > 0.999) v = 0.999;
+      double sc = 256.0 * v;
+      rgb[i] = isnan(sc) ? (uint8_t)0 : (uint8_t)(sc < 0.0 ? 0.0 : (sc > 255.0 ? 255.0 : sc));
+    } else {
+      image[i] = (float)sum;
+    }
+  }
+}
+
+hipError_t sol_launch_bloom(float* image, double* a, double* b, const double* weights, uint32_t k, uint32_t width, uint32_t height,
+                            double threshold, double max_intensity, uint8_t* rgb, uint32_t spp, hipStream_t stream) {
+  const uint32_t npix = width * height;
+  uint32_t grid = (npix + 255u) / 256u;
+  if (grid > 8192u) grid = 8192u;
+  if (grid == 0) return hipSuccess;
+  hipLaunchKernelGGL(sol_bloom_bright_kernel, dim3(grid), dim3(256), 0, stream, image, a, npix, threshold, max_intensity);
+  hipLaunchKernelGGL((sol_bloom_blur_kernel<false>), dim3(grid), dim3(256), 0, stream, a, b, width, height, weights, k);
+  hipLaunchKernelGGL((sol_bloom_blur_kernel<true>), dim3(grid), dim3(256), 0, stream, b, a, width, height, weights, k);
+  hipLaunchKernelGGL(sol_bloom_finish_kernel, dim3(grid), dim3(256), 0, stream, image, a, rgb, npix * 3u, spp);
+  return hipGetLastError();
+}
+
 // ---- launch wrappers (called from sol_api.cpp) ----
 hipError_t sol_launch_resolve(float* acc, const float* partial, uint32_t n_floats, uint32_t n_chunks, hipStream_t stream) {
   uint32_t grid = (n_floats + 255u) / 256u;

@@ -226,11 +226,24 @@ struct RenderImageStrategy {
   bool should_generate_image(uint32_t sample, uint32_t total, double now_s, double last_s) const;
 };
 
+// src/post/mod.rs:45-55. Post-processors run on the device (sol_tonemap_rgb8, sol_bloom*); OidnPostProcessor is not built
+// (a third-party denoiser binary, out of scope).
+struct PostProcessors {
+  enum Kind { Nop, Bloom } kind = Nop;
+  double kernel_size_fraction = 0, threshold = 0, max_intensity = 0;  // Bloom
+};
+struct NopPostProcessor { static PostProcessors create() { return {}; } };  // src/post/nop.rs:11-17
+struct BloomPostProcessor {
+  // src/post/bloom.rs:27-47: throws std::invalid_argument("kernel_size_fraction must be between 0 and 0.5");
+  // a NaN threshold / max_intensity means None (defaults |(1,1,1)| and f64::MAX)
+  static PostProcessors create(double kernel_size_fraction, double threshold = std::nan(""), double max_intensity = std::nan(""));
+};
+
 struct RenderConfig {
   size_t width = 300, height = 200;
   uint32_t samples_per_pixel = 50;
   Shaders shader = PathTracingShader::create(50);
-  // post_processors: only the default NopPostProcessor is on this side of the scope line
+  std::vector<PostProcessors> post_processors{NopPostProcessor::create()};  // src/renderer/mod.rs:35,49
   RenderImageStrategy render_image_strategy;
   uint64_t seed = 0x5017A1Eull;  // the reference has no seed (entropy-seeded fastrand); the build adds one
 };

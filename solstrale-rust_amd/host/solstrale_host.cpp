@@ -506,6 +506,17 @@ void to_rgb_color(const double col[3], uint32_t spp, uint8_t out[3]) {
   }
 }
 
+PostProcessors BloomPostProcessor::create(double kernel_size_fraction, double threshold, double max_intensity) {
+  if (!(kernel_size_fraction >= 0. && kernel_size_fraction <= 0.5))
+    throw std::invalid_argument("kernel_size_fraction must be between 0 and 0.5");
+  PostProcessors p;
+  p.kind = PostProcessors::Bloom;
+  p.kernel_size_fraction = kernel_size_fraction;
+  p.threshold = std::isnan(threshold) ? Vec3{1., 1., 1.}.length() : threshold;
+  p.max_intensity = std::isnan(max_intensity) ? std::numeric_limits<double>::max() : max_intensity;
+  return p;
+}
+
 // ---- ray_trace (src/lib.rs:93-99, src/renderer/mod.rs:140-162,209-358) ---------------------------------------
 std::string ray_trace(const Scene& scene, const std::function<void(RenderProgress&&)>& output,
                       const std::function<bool()>& abort, int device) {
@@ -524,7 +535,6 @@ std::string ray_trace(const Scene& scene, const std::function<void(RenderProgres
   const RenderConfig& rc = scene.render_config;
   const uint32_t spp = rc.samples_per_pixel;
   const size_t npix = rc.width * rc.height;
-  std::vector<float> sums(npix * 3);
   using clk = std::chrono::steady_clock;
   auto t0 = clk::now();
   auto secs = [&](clk::time_point t) { return std::chrono::duration<double>(t - t0).count(); };
@@ -547,14 +557,26 @@ std::string ray_trace(const Scene& scene, const std::function<void(RenderProgres
       if (last_of_batch && rc.render_image_strategy.should_generate_image(s, spp, now, last_image_time)) {
         last_image_time = now;
         if (abort && abort()) return "";
-        if (sol_read(dev, sums.data()) != SOL_OK) return sol_last_error();
-        p.has_image = true;
-        p.width = (uint32_t)rc.width;
-        p.height = (uint32_t)rc.height;
-        p.render_image.resize(npix * 3);
-        for (size_t i = 0; i < npix; ++i) {  // NopPostProcessor (src/post/nop.rs:19-34)
-          double c[3] = {sums[i * 3], sums[i * 3 + 1], sums[i * 3 + 2]};
-          to_rgb_color(c, s, &p.render_image[i * 3]);
+        // post-processor chain (renderer/mod.rs:307-337) on the device: every processor but the last transforms the sums
+        // (intermediate_post_process), the last one produces the image; an empty list produces none
+        if (!rc.post_processors.empty()) {
+          void* img = nullptr;
+          if (sol_resolve_image(dev, &img) != SOL_OK) return sol_last_error();
+          for (size_t k = 0; k + 1 < rc.post_processors.size(); ++k) {
+            const PostProcessors& pp = rc.post_processors[k];
+            if (pp.kind == PostProcessors::Bloom &&
+                sol_bloom(dev, img, s, pp.kernel_size_fraction, pp.threshold, pp.max_intensity) != SOL_OK)
+              return sol_last_error();  // Nop: intermediate_post_process is the identity (nop.rs:36-46)
+          }
+          const PostProcessors& last = rc.post_processors.back();
+          p.render_image.resize(npix * 3);
+          int rcode = last.kind == PostProcessors::Bloom
+                          ? sol_bloom_rgb8(dev, img, s, last.kernel_size_fraction, last.threshold, last.max_intensity, p.render_image.data())
+                          : sol_tonemap_rgb8(dev, img, s, p.render_image.data());
+          if (rcode != SOL_OK) return sol_last_error();
+          p.has_image = true;
+          p.width = (uint32_t)rc.width;
+          p.height = (uint32_t)rc.height;
         }
       }
       double elapsed = std::max(now, 1e-9);

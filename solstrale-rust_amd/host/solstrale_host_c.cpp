@@ -257,6 +257,19 @@ int solh_ray_trace(SolhBuilder* b, uint32_t spp, uint64_t seed, int strategy, do
   });
 }
 
+int solh_set_post_processors(SolhBuilder* b, int n, const int* kinds, const double* params) {
+  return guarded([&] {
+    std::vector<PostProcessors> pp;
+    for (int i = 0; i < n; ++i) {
+      if (kinds[i] == 0) pp.push_back(NopPostProcessor::create());
+      else if (kinds[i] == 1) pp.push_back(BloomPostProcessor::create(params[3 * i], params[3 * i + 1], params[3 * i + 2]));
+      else throw std::runtime_error("solh_set_post_processors: unknown post-processor kind");
+    }
+    b->scene.render_config.post_processors = std::move(pp);
+    return 0;
+  });
+}
+
 void solh_abi_sizes(uint32_t out[11]) {
   const size_t s[11] = {sizeof(SolAabb), sizeof(SolBvhNode), sizeof(SolSphere), sizeof(SolQuad), sizeof(SolTriangle),
                         sizeof(SolMedium), sizeof(SolMaterial), sizeof(SolTexture), sizeof(SolCamera), sizeof(SolSceneDesc),

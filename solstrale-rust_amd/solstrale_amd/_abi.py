@@ -145,6 +145,10 @@ def load_hip():
     _sig(lib, "sol_read", C.c_int, [P, C.POINTER(C.c_float)])
     _sig(lib, "sol_unpermute", C.c_int, [P, C.c_void_p, C.c_int, C.c_void_p])
     _sig(lib, "sol_tonemap_rgb8", C.c_int, [P, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint8)])
+    _sig(lib, "sol_resolve_image", C.c_int, [P, C.POINTER(C.c_void_p)])
+    _sig(lib, "sol_bloom", C.c_int, [P, C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_double])
+    _sig(lib, "sol_bloom_rgb8", C.c_int, [P, C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_uint8)])
+    _sig(lib, "sol_gaussian_blur_weights", C.c_int, [C.c_uint32, C.c_double, C.POINTER(C.c_double)])
     _sig(lib, "sol_stats", C.c_int, [P, C.POINTER(SolStats)])
     _sig(lib, "sol_record_sizes", C.c_int, [C.POINTER(C.c_uint32)])
     _sig(lib, "sol_last_error", C.c_char_p, [])
@@ -160,7 +164,7 @@ HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol
                "sol_accum_floats", "sol_accum_ptr", "sol_scene_bind_accum", "sol_scene_set_stream", "sol_clear",
                "sol_render", "sol_render_counted", "sol_sync", "sol_read", "sol_unpermute", "sol_tonemap_rgb8",
                "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms",
-               "sol_debug_path"]
+               "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights"]
 
 
 def load_host():
@@ -198,6 +202,7 @@ def load_host():
          [B, I, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _D3, D, D, _D3, _D3, _D3])
     _sig(lib, "solh_tree_depth", C.c_uint32, [B])
     _sig(lib, "solh_ray_trace", I, [B, C.c_uint32, C.c_uint64, I, D, I, PROGRESS_FN, ABORT_FN, C.c_void_p])
+    _sig(lib, "solh_set_post_processors", I, [B, I, C.POINTER(C.c_int), C.POINTER(C.c_double)])
     _sig(lib, "solh_abi_sizes", None, [C.POINTER(C.c_uint32)])
     _sig(lib, "solh_to_rgb_color", None, [_D3, C.c_uint32, C.POINTER(C.c_uint8)])
     _libs["host"] = lib
@@ -208,7 +213,7 @@ HOST_SYMBOLS = ["solh_builder_new", "solh_builder_free", "solh_last_error", "sol
                 "solh_image_map", "solh_normal_texture", "solh_lambertian", "solh_metal", "solh_dielectric",
                 "solh_diffuse_light", "solh_blend", "solh_sphere", "solh_quad", "solh_box", "solh_triangle",
                 "solh_triangles", "solh_spheres", "solh_constant_medium", "solh_bvh", "solh_bvh_range", "solh_finish",
-                "solh_tree_depth", "solh_ray_trace", "solh_abi_sizes", "solh_to_rgb_color"]
+                "solh_tree_depth", "solh_ray_trace", "solh_abi_sizes", "solh_to_rgb_color", "solh_set_post_processors"]
 
 
 def d3(v):

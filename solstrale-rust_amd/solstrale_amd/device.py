@@ -108,6 +108,30 @@ class DeviceScene:
                                             out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
+    def resolve_image(self):
+        """Device pointer of the scene's own row-major image (W*H*3 floats) after un-permuting its accumulators."""
+        p = C.c_void_p()
+        self._chk(self.lib.sol_resolve_image(self.h, C.byref(p)))
+        return p.value
+
+    BLOOM_DEFAULT_THRESHOLD = 3.0 ** 0.5  # Vec3::new(1., 1., 1.).length() (bloom.rs:39)
+    BLOOM_DEFAULT_MAX = 1.7976931348623157e308  # f64::MAX (bloom.rs:40)
+
+    def bloom(self, image_ptr, num_samples, kernel_size_fraction, threshold=None, max_intensity=None):
+        """BloomPostProcessor::intermediate_post_process on the device image, in place."""
+        self._chk(self.lib.sol_bloom(self.h, C.c_void_p(image_ptr), num_samples, kernel_size_fraction,
+                                     self.BLOOM_DEFAULT_THRESHOLD if threshold is None else threshold,
+                                     self.BLOOM_DEFAULT_MAX if max_intensity is None else max_intensity))
+
+    def bloom_rgb8(self, image_ptr, num_samples, kernel_size_fraction, threshold=None, max_intensity=None):
+        """BloomPostProcessor::post_process of the device image -> RGB8 (H, W, 3)."""
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        self._chk(self.lib.sol_bloom_rgb8(self.h, C.c_void_p(image_ptr), num_samples, kernel_size_fraction,
+                                          self.BLOOM_DEFAULT_THRESHOLD if threshold is None else threshold,
+                                          self.BLOOM_DEFAULT_MAX if max_intensity is None else max_intensity,
+                                          out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
     def debug_path(self, x, y, sample, seed, max_rows=80):
         """Rays of one path: rows of (o xyz, d xyz, t, ref bits, dfs bits, depth, 0, 0); returns (rows, colour)."""
         buf = np.zeros((max_rows, 12), dtype=np.float32)

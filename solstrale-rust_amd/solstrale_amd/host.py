@@ -49,16 +49,29 @@ class CameraConfig:
         self.up = up
 
 
+def NopPostProcessor():
+    """src/post/nop.rs:11-17"""
+    return (0, (0., 0., 0.))
+
+
+def BloomPostProcessor(kernel_size_fraction, threshold=None, max_intensity=None):
+    """src/post/bloom.rs:27-47 (None = the reference's default; the range check happens where the chain is installed)."""
+    nan = float("nan")
+    return (1, (float(kernel_size_fraction), nan if threshold is None else float(threshold),
+                nan if max_intensity is None else float(max_intensity)))
+
+
 class RenderConfig:
-    """src/renderer/mod.rs:26-52 (post_processors: Nop only; seed is the build's addition)."""
+    """src/renderer/mod.rs:26-52 (seed is the build's addition; OidnPostProcessor is not built)."""
 
     def __init__(self, width=300, height=200, samples_per_pixel=50, shader=(_abi.SHADER_PATH_TRACING, 50),
-                 seed=0x5017A1E):
+                 seed=0x5017A1E, post_processors=None):
         self.width = width
         self.height = height
         self.samples_per_pixel = samples_per_pixel
         self.shader = shader
         self.seed = seed
+        self.post_processors = [NopPostProcessor()] if post_processors is None else list(post_processors)
 
 
 def PathTracingShader(max_depth):
@@ -117,6 +130,11 @@ class Scene:
         cb = _abi.PROGRESS_FN(_progress)
         ab = _abi.ABORT_FN(_abort)
         strat = {"every_sample": 0, "interval": 1, "only_final": 2}[strategy]
+        pp = rc.post_processors
+        kinds = (C.c_int * max(1, len(pp)))(*[k for k, _ in pp])
+        params = (C.c_double * max(1, 3 * len(pp)))(*[x for _, prm in pp for x in prm])
+        if b.lib.solh_set_post_processors(b.h, len(pp), kinds, params) != 0:
+            raise HostError(b.lib.solh_last_error().decode())
         rc_ = b.lib.solh_ray_trace(b.h, rc.samples_per_pixel, rc.seed, strat, interval_seconds, device, cb, ab, None)
         if rc_ != 0:
             raise HostError(b.lib.solh_last_error().decode())

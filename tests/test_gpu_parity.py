@@ -58,6 +58,24 @@ def test_c3_sponza_class_crop():
     assert_parity(sc, 4, rect=(0, 952, 128, 1080))  # a corner: floor + walls, other BVH regions
 
 
+@pytest.mark.parametrize("env", [{"SOL_BVH": "ref"}, {"SOL_BVH": "sah"}, {"SOL_SWITCH": "0"}, {"SOL_SWITCH": "40"},
+                                 {"SOL_BVH": "sah", "SOL_SLOTS": "octant"}, {"SOL_KERNEL": "v2"}, {"SOL_KERNEL": "v3"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_tree_and_schedule_variants_are_bit_identical(env, monkeypatch):
+    """The closest hit does not depend on the tree (reference topology, SAH rebuild, slot assignment), and the image is a
+    pure function of (scene, seed): every world-tree choice, every search/shade switch threshold and every kernel variant
+    must reproduce the default build's frame bit for bit ("tree independence")."""
+    frames = {}
+    for name, make in (("c2", scenes.cornell_spheres), ("c3", scenes.sponza_like)):
+        sc = make(RenderConfig(480, 270, 16))
+        frames[name] = (sc, gpu_render(sc, 16))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, (sc, want) in frames.items():
+        got = gpu_render(sc, 16)
+        assert (got == want).all(), (name, env, int((got != want).sum()))
+
+
 def test_c5_shape_dielectric_metal_crop():
     """configs[4] shape: triangle mesh + dielectric and metal spheres; crop against the oracle."""
     assert_parity(_atrium_with_bsdfs(RenderConfig(640, 360, 16)), 16, rect=(256, 116, 384, 244))
