@@ -74,6 +74,15 @@ uint32_t solh_tree_depth(const SolhBuilder* b);
  * callback per sample index (image pointer non-NULL when the strategy produced one; RGB8, row 0 top),
  * abort callback polled between batches (may be NULL). strategy: 0 EverySample, 1 Interval(seconds),
  * 2 OnlyFinal. Returns 0, or negative with solh_last_error() = the reference's error string. */
+/* Obj::new(path, filename).load(transformation, default_material) (src/loader/obj.rs:29-136): returns the hittable id of the
+ * Bvh of the model's triangles. default_material < 0 = None (white Lambertian). Image files named by the MTL are decoded
+ * by `decoder` (the reference uses the `image` crate): it returns 0 and a W*H*3 RGB8 buffer that stays valid until its next
+ * call, 1 when the file cannot be opened, 2 when it cannot be decoded. Errors carry the reference's strings:
+ * "failed to load obj model from ..", "failed to load MTL file for ..", "Failed to open image texture ..: ..". */
+typedef int (*solh_image_decoder)(void* user, const char* path, uint32_t* width, uint32_t* height, const uint8_t** rgb8);
+int solh_load_obj(SolhBuilder* b, const char* path, const char* filename, int transform, int default_material,
+                  solh_image_decoder decoder, void* user);
+
 /* RenderConfig::post_processors (src/renderer/mod.rs:35) for the following solh_ray_trace calls: kinds[i] 0 = NopPostProcessor,
  * 1 = BloomPostProcessor with params[3i..3i+2] = kernel_size_fraction, threshold, max_intensity (NaN = None); n = 0: no image
  * is produced. The default is one NopPostProcessor. Errors carry the reference's strings

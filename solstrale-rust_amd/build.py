@@ -17,7 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_SRC = ["csrc/sol_render.hip", "csrc/sol_wavefront.hip", "csrc/sol_aux.hip", "csrc/sol_api.cpp"]
 HIP_DEPS = HIP_SRC + ["csrc/sol_types.h", "csrc/sol_math.h", "csrc/sol_trace.h", "csrc/sol_shade.h", "csrc/sol_path.h", "csrc/sol_launch.h",
                       "../include/solstrale_hip.h"]
-HOST_SRC = ["host/solstrale_host.cpp", "host/solstrale_host_c.cpp"]
+HOST_SRC = ["host/solstrale_host.cpp", "host/solstrale_obj.cpp", "host/solstrale_host_c.cpp"]
 HOST_DEPS = HOST_SRC + ["host/solstrale.hpp", "../include/solstrale_hip.h", "../include/solstrale_host.h"]
 
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",

@@ -203,6 +203,20 @@ struct Bvh {
 };
 std::vector<Hittables> get_lights(const Hittables& h);  // Hittable::get_lights, depth-first
 
+// ---- loader (src/loader/obj.rs) -------------------------------------------------------------------------
+// File decoding (the `image` crate in the reference) is supplied by the caller: decode(path, what) returns the RGB8 image
+// or throws std::runtime_error carrying the reference's message, "Failed to open|load|decode {what} texture {path}: .."
+// with what = "image" (ImageMap::load, texture.rs:137-153) or "bump" (load_bump_map, texture.rs:53-65).
+using ImageDecoder = std::function<std::shared_ptr<const RgbImage>(const std::string& path, const char* what)>;
+struct Obj {
+  std::string path, filename;
+  Obj(std::string p, std::string f) : path(std::move(p)), filename(std::move(f)) {}  // Obj::new (obj.rs:29-34)
+  // Loader::load (obj.rs:38-136): every material Lambertian (Kd / map_Kd, map_bump with normal-vs-height detection),
+  // `default_material` (nullptr = white Lambertian) for faces without one, all triangles in one Bvh. Throws
+  // std::runtime_error("failed to load obj model from {path}{filename}") / ("failed to load MTL file for ..").
+  Hittables load(const Transformer& transformation, Materials default_material, const ImageDecoder& decode) const;
+};
+
 // ---- camera / render config (src/camera.rs, src/renderer/mod.rs) -------------------------------------
 struct CameraConfig {
   double vertical_fov_degrees = 50.0;

@@ -257,6 +257,26 @@ int solh_ray_trace(SolhBuilder* b, uint32_t spp, uint64_t seed, int strategy, do
   });
 }
 
+int solh_load_obj(SolhBuilder* b, const char* path, const char* filename, int transform, int default_material,
+                  solh_image_decoder decoder, void* user) {
+  return guarded([&] {
+    ImageDecoder dec = [&](const std::string& p, const char* what) -> std::shared_ptr<const RgbImage> {
+      uint32_t w = 0, h = 0;
+      const uint8_t* data = nullptr;
+      const int rc = decoder ? decoder(user, p.c_str(), &w, &h, &data) : 1;
+      if (rc == 1) throw std::runtime_error(std::string("Failed to open ") + what + " texture " + p + ": No such file or directory (os error 2)");
+      if (rc != 0 || !data || !w || !h) throw std::runtime_error(std::string("Failed to decode ") + what + " texture " + p + ": unsupported or corrupt image");
+      auto img = std::make_shared<RgbImage>();
+      img->width = w; img->height = h;
+      img->data.assign(data, data + (size_t)w * h * 3);
+      return img;
+    };
+    Materials dm = default_material < 0 ? nullptr : b->mat(default_material);
+    b->hittables.push_back(Obj(path, filename).load(b->tf(transform), dm, dec));
+    return (int)b->hittables.size() - 1;
+  });
+}
+
 int solh_set_post_processors(SolhBuilder* b, int n, const int* kinds, const double* params) {
   return guarded([&] {
     std::vector<PostProcessors> pp;

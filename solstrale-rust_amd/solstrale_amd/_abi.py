@@ -110,6 +110,8 @@ ABI_STRUCTS = [SolAabb, SolBvhNode, SolSphere, SolQuad, SolTriangle, SolMedium, 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_uint8), C.c_uint32,
                           C.c_uint32)
 ABORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+IMAGE_DECODER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                               C.POINTER(C.POINTER(C.c_uint8)))
 
 _D3 = C.POINTER(C.c_double)
 _libs = {}
@@ -202,6 +204,7 @@ def load_host():
          [B, I, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _D3, D, D, _D3, _D3, _D3])
     _sig(lib, "solh_tree_depth", C.c_uint32, [B])
     _sig(lib, "solh_ray_trace", I, [B, C.c_uint32, C.c_uint64, I, D, I, PROGRESS_FN, ABORT_FN, C.c_void_p])
+    _sig(lib, "solh_load_obj", I, [B, C.c_char_p, C.c_char_p, I, I, IMAGE_DECODER_FN, C.c_void_p])
     _sig(lib, "solh_set_post_processors", I, [B, I, C.POINTER(C.c_int), C.POINTER(C.c_double)])
     _sig(lib, "solh_abi_sizes", None, [C.POINTER(C.c_uint32)])
     _sig(lib, "solh_to_rgb_color", None, [_D3, C.c_uint32, C.POINTER(C.c_uint8)])
@@ -213,7 +216,7 @@ HOST_SYMBOLS = ["solh_builder_new", "solh_builder_free", "solh_last_error", "sol
                 "solh_image_map", "solh_normal_texture", "solh_lambertian", "solh_metal", "solh_dielectric",
                 "solh_diffuse_light", "solh_blend", "solh_sphere", "solh_quad", "solh_box", "solh_triangle",
                 "solh_triangles", "solh_spheres", "solh_constant_medium", "solh_bvh", "solh_bvh_range", "solh_finish",
-                "solh_tree_depth", "solh_ray_trace", "solh_abi_sizes", "solh_to_rgb_color", "solh_set_post_processors"]
+                "solh_tree_depth", "solh_ray_trace", "solh_abi_sizes", "solh_to_rgb_color", "solh_set_post_processors", "solh_load_obj"]
 
 
 def d3(v):

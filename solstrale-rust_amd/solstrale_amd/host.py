@@ -6,6 +6,7 @@ All geometry work (transforms, boxes, BVH build, flattening, Camera::new) happen
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -237,6 +238,29 @@ class SceneBuilder:
         m = np.ascontiguousarray(np.broadcast_to(np.asarray(materials, dtype=np.int32), (n,)))
         first = self._chk(self.lib.solh_spheres(self.h, n, c.ctypes.data, r.ctypes.data, m.ctypes.data))
         return first, n
+
+    def load_obj(self, path, filename, transformation=None, default_material=None):
+        """`Obj::new(path, filename).load(transformation, default_material)` (src/loader/obj.rs:29-136) -> hittable id of the
+        model's Bvh. Image files are decoded here with Pillow (the reference: `image` crate) and handed over as RGB8."""
+        from PIL import Image
+        keep = []
+
+        def _decode(_user, cpath, pw, ph, pdata):
+            fn = cpath.decode()
+            if not os.path.isfile(fn):
+                return 1
+            try:
+                a = np.ascontiguousarray(np.asarray(Image.open(fn).convert("RGB"), dtype=np.uint8))
+            except Exception:
+                return 2
+            keep.append(a)
+            pw[0], ph[0] = a.shape[1], a.shape[0]
+            pdata[0] = a.ctypes.data_as(C.POINTER(C.c_uint8))
+            return 0
+
+        cb = _abi.IMAGE_DECODER_FN(_decode)
+        return self._chk(self.lib.solh_load_obj(self.h, path.encode(), filename.encode(), self._tf(transformation),
+                                                -1 if default_material is None else default_material, cb, None))
 
     def ConstantMedium(self, boundary, density, color):
         return self._chk(self.lib.solh_constant_medium(self.h, boundary, density, _abi.d3(color)))

@@ -281,6 +281,41 @@ def create_uv_scene(render_config):
     return b.finish(b.Bvh(world), cam, (.2, .3, .5), render_config)
 
 
+def _resource_dir(name):
+    """The reference's `resources/<name>/` prefix (its loaders concatenate path + filename, src/loader/obj.rs:50)."""
+    return os.path.join(RESOURCES, name) + os.sep
+
+
+def create_obj_scene(render_config):
+    """tests/scenes.rs:318-352: the spider model (resources/spider/spider.obj, 5 textured materials) over a textured ground."""
+    b = SceneBuilder()
+    cam = CameraConfig(30., 20., (-250., 30., 150.), (-50., 0., 0.), (0., 1., 0.))
+    light = b.DiffuseLight(15., 15., 15.)
+    world = [b.Sphere((-100., 100., 40.), 35., light), b.load_obj(_resource_dir("spider"), "spider.obj")]
+    ground = b.Lambertian(b.ImageMap(load_image("textures/tex.jpg")))
+    world.append(b.Quad((-200., -30., -200.), (400., 0., 0.), (0., 0., 400.), ground))
+    return b.finish(b.Bvh(world), cam, (.2, .3, .5), render_config)
+
+
+def create_obj_with_box(render_config, filename, path=None):
+    """tests/scenes.rs:355-381 (default material: red Lambertian)."""
+    b = SceneBuilder()
+    cam = CameraConfig(30., 0., (2., 1., 3.), (0., 0., 0.), (0., 1., 0.))
+    light = b.DiffuseLight(15., 15., 15.)
+    red = b.Lambertian(b.SolidColor(1., 0., 0.))
+    world = [b.Sphere((-100., 100., 40.), 35., light), b.load_obj(path or _resource_dir("obj"), filename, None, red)]
+    return b.finish(b.Bvh(world), cam, (.2, .3, .5), render_config)
+
+
+def create_obj_with_triangle(render_config, filename, path=None):
+    """tests/scenes.rs:384-409"""
+    b = SceneBuilder()
+    cam = CameraConfig(30., 0., (0., 0., 2.), (0., 0., 0.), (0., 1., 0.))
+    light = b.DiffuseLight(15., 15., 15.)
+    world = [b.Sphere((100., 0., 100.), 35., light), b.load_obj(path or _resource_dir("obj"), filename)]
+    return b.finish(b.Bvh(world), cam, (0., 0., 0.), render_config)
+
+
 def create_normal_mapping_scene(render_config, light_pos, normal_mapping_enabled):
     """tests/scenes.rs:233-280"""
     b = SceneBuilder()

@@ -31,4 +31,10 @@ CASES = [
     ("blended_materials_0", lambda s: scenes.create_blend_material_scene(_rc(300, 300, s), 0.), 300, 300, 50, 12),
     ("blended_materials_0.5", lambda s: scenes.create_blend_material_scene(_rc(300, 300, s), 0.5), 300, 300, 50, 12),
     ("blended_materials_1", lambda s: scenes.create_blend_material_scene(_rc(300, 300, s), 1.), 300, 300, 50, 12),
+    # Obj loader (src/loader/obj.rs): tests/integration_tests.rs:63-98,195-217
+    ("obj", lambda s: scenes.create_obj_scene(_rc(200, 100, s)), 200, 100, 20, 20),
+    ("obj_default", lambda s: scenes.create_obj_with_box(_rc(200, 100, s), "box.obj"), 200, 100, 50, 16),
+    ("obj_diffuse", lambda s: scenes.create_obj_with_box(_rc(200, 100, s), "boxWithMat.obj"), 200, 100, 50, 16),
+    ("obj_normal_map", lambda s: scenes.create_obj_with_triangle(_rc(300, 300, s), "triWithNormalMap.obj"), 300, 300, 50, 12),
+    ("obj_height_map", lambda s: scenes.create_obj_with_triangle(_rc(300, 300, s), "triWithHeightMap.obj"), 300, 300, 50, 12),
 ]
