@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3"])
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -89,6 +89,14 @@ def main():
         w, h, spp0 = 1920, 1080, 512
         name = f"C3 Sponza-class procedural atrium, {scenes.SPONZA_TRIANGLES} triangles, 24 Lambertian materials (8 image-textured), 1 quad light"
         make = lambda rc: scenes.sponza_like(rc)
+    elif args.workload == "c4":  # configs[3]: C3's scene at 4K, 1024 spp over 8 GPUs = 128 spp of per-GPU work
+        w, h, spp0 = 3840, 2160, 128
+        name = f"C4 Sponza-class procedural atrium, {scenes.SPONZA_TRIANGLES} triangles, 4K (BASELINE: 1024 spp over 8 GPUs = 128 spp per GPU)"
+        make = lambda rc: scenes.sponza_like(rc)
+    elif args.workload == "c5":  # configs[4]: 2048 spp over 8 GPUs = 256 spp of per-GPU work
+        w, h, spp0 = 1920, 1080, 256
+        name = f"C5 statue-class displaced mesh, ~{scenes.STATUE_TRIANGLES} triangles, Metal(0.1) + Dielectric(1.5), 1 quad light (BASELINE: 2048 spp over 8 GPUs = 256 spp per GPU)"
+        make = lambda rc: scenes.statue_like(rc)
     elif args.workload == "c2":
         w, h, spp0 = 1920, 1080, 256
         name = "C2 Cornell box + 10000 Lambertian spheres"

@@ -224,6 +224,64 @@ def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1
     return b.finish(world, cam, (0.35, 0.5, 0.75), rc)
 
 
+STATUE_TRIANGLES = 1_090_000
+
+
+def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES):
+    """C5 stand-in: a procedurally displaced "statue" of about 1.09 M triangles - a noise-displaced body of
+    Metal(fuzz 0.1), a Dielectric(1.5) head and a glass orb, a Lambertian plinth and drapery - on a floor quad under one
+    quad light, constant background. (The Happy Buddha mesh and an HDRI light are not available / not in the reference.)"""
+    rc = render_config or RenderConfig(width=1920, height=1080, samples_per_pixel=2048)
+    b = SceneBuilder()
+    metal = b.Metal(b.SolidColor(.85, .7, .45), None, 0.1)
+    glass = b.Dielectric(b.SolidColor(1., 1., 1.), None, 1.5)
+    stone = b.Lambertian(b.SolidColor(.55, .52, .5))
+    cloth = b.Lambertian(b.SolidColor(.6, .15, .12))
+
+    def noise(u, v, k, amp):  # smooth, periodic in u
+        return amp * (np.sin(2 * np.pi * (k * u) + 7.0 * v) * np.cos(2 * np.pi * (0.5 * k * v) + 3.0 * u) +
+                      0.5 * np.sin(2 * np.pi * (3 * k * u) + 1.3) * np.sin(2 * np.pi * (2 * k * v)))
+
+    def body(u, v):  # torso: a lathe profile with folds
+        y = 1.0 + 3.2 * v
+        r = (0.95 - 0.35 * v + 0.25 * np.sin(np.pi * v) ** 2) * (1.0 + noise(u, v, 6, 0.06)) + 0.05 * np.sin(40 * np.pi * v)
+        return r * np.cos(2 * np.pi * u), y, r * np.sin(2 * np.pi * u)
+
+    def head(u, v):
+        th = np.pi * (0.02 + 0.96 * v)
+        r = 0.55 * (1.0 + noise(u, v, 4, 0.05))
+        return r * np.sin(th) * np.cos(2 * np.pi * u), 4.75 - r * np.cos(th), r * np.sin(th) * np.sin(2 * np.pi * u)
+
+    def plinth(u, v):
+        y = 1.0 * v
+        r = 1.5 * (1.0 - 0.15 * v) * (1.0 + 0.03 * np.sign(np.sin(16 * np.pi * u)))
+        return r * np.cos(2 * np.pi * u), y, r * np.sin(2 * np.pi * u)
+
+    def drape(u, v):
+        ang = 2 * np.pi * (0.15 + 0.5 * u)
+        r = 1.25 + 0.12 * np.sin(18 * np.pi * u) * (0.3 + v)
+        return r * np.cos(ang), 3.4 - 2.3 * v + 0.05 * np.sin(9 * np.pi * u), r * np.sin(ang)
+
+    parts = [(0.60, body, metal), (0.16, head, glass), (0.12, plinth, stone), (0.12, drape, cloth)]
+    tris, uvs, mids = [], [], []
+    made = 0
+    for k, (w, f, m) in enumerate(parts):
+        share = n_triangles * w if k + 1 < len(parts) else n_triangles - made
+        cells = max(1, int(share // 2))
+        nu = max(1, int(round(math.sqrt(cells * 2.0))))
+        nv = max(1, cells // nu)
+        t, uv = _grid(f, nu, nv)
+        tris.append(t), uvs.append(uv), mids.append(np.full(len(t), m, dtype=np.int32))
+        made += len(t)
+    first, n = b.triangles(np.concatenate(tris), np.concatenate(mids), np.concatenate(uvs))
+    model = b.Bvh_range(first, n)
+    orb = b.Sphere((2.2, 0.7, 1.2), 0.7, glass)
+    floor = b.Quad((-12., 0., -12.), (24., 0, 0), (0, 0, 24.), b.Lambertian(b.SolidColor(.4, .42, .45)))
+    light = b.Quad((-2.5, 8.5, -1.0), (5., 0, 0), (0, 0, 4.), b.DiffuseLight(20., 19., 17.))
+    cam = CameraConfig(vertical_fov_degrees=38., aperture_size=0., look_from=(4.5, 3.6, 8.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
+    return b.finish(b.Bvh([model, orb, floor, light]), cam, (0.25, 0.3, 0.4), rc)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The reference's test scenes (tests/scenes.rs)
 # ---------------------------------------------------------------------------------------------------------------

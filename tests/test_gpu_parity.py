@@ -81,6 +81,14 @@ def test_c5_shape_dielectric_metal_crop():
     assert_parity(_atrium_with_bsdfs(RenderConfig(640, 360, 16)), 16, rect=(256, 116, 384, 244))
 
 
+def test_c5_statue_class_crop():
+    """configs[4] stand-in at full size: ~1.09 M triangles, Metal(0.1) body, Dielectric(1.5) head and orb; 1080p, 128x128 crops."""
+    sc = scenes.statue_like(RenderConfig(1920, 1080, 16))
+    assert abs(sc.desc.n_triangles - scenes.STATUE_TRIANGLES) < 2000
+    assert_parity(sc, 16, rect=(896, 476, 1024, 604))   # body + drapery
+    assert_parity(sc, 8, rect=(900, 60, 1028, 188))     # glass head (x 830-1020, y 55-255) against the background
+
+
 def _atrium_with_bsdfs(rc):
     b = SceneBuilder()
     mats = [b.Lambertian(b.SolidColor(.7, .6, .5)), b.Lambertian(b.SolidColor(.3, .5, .7))]
