@@ -3,20 +3,18 @@
 //
 // Two persistent kernels with bit-identical results (same device functions, sol_path.h):
 //
-//  sol_render_pool_kernel (default) -- wave-private WAVEFRONT. Every wave owns a pool of path slots in global memory
-//    (112 B of state per slot) and alternates two dense stages, with no workgroup barrier and no atomics except the global
-//    work counter:
-//      stage A  shade / regenerate : the wave sweeps its slots 64 at a time; a slot with a finished search is shaded (scatter,
-//               light/BSDF mixture pdf, throughput update or termination), a terminated path starts the next sample of its
-//               work item (camera ray) or takes a new (pixel, 16-sample chunk) item; live rays are COMPACTED into the
-//               wave's ray queue in LDS by ballot + popcount prefix;
-//      stage B  intersect : lanes take rays from the queue and search the BVH (ordered traversal, LDS-resident per-lane
-//               stack); whenever enough lanes have finished they are REFILLED from the queue (ballot/prefix again), so the
-//               traversal loop - 3/4 of all instructions - runs with nearly all lanes busy; only (origin, direction, hit)
-//               live in registers here, the rest of the path state stays in memory.
-//  sol_render_kernel (SOL_KERNEL=v1) -- the round-1 bring-up kernel: one path per lane from camera ray to termination.
+//  sol_render_kernel (the product path, SOL_KERNEL=v1) -- one path per lane, state in registers. A wave alternates between
+//    the search loop (one resumable BVH step per turn, per-lane stack in LDS) and the service block (shade the closest hit,
+//    fetch work, generate the next camera ray); it leaves the search loop as soon as too few of its lanes are still
+//    searching while others wait (RenderParams::switch_below), unfinished searches keep their state across the service
+//    block. DESIGN.md 3.
+//  sol_render_pool_kernel (SOL_KERNEL=v2, A/B only) -- wave-private WAVEFRONT over a pool of path slots in global memory
+//    (112 B of state per slot): stage A shades / regenerates 64 slots at a time and compacts live rays into an LDS queue by
+//    ballot + popcount prefix; stage B searches with refill of idle lanes from the queue. Higher search occupancy, but the
+//    state traffic and the lower residency (3 waves/SIMD) cost more than they buy (measurements in sol_api.cpp).
+//  (The two-kernel wavefront, SOL_KERNEL=v3, lives in sol_wavefront.hip.)
 //
-// In both, a work item's 16 samples are summed in sample order by whoever owns the item and written once; no float atomic
+// In all of them a work item's 16 samples are summed in sample order by whoever owns the item and written once; no float atomic
 // touches the accumulator, so the image is a pure function of (scene, seed), bit-identical for any tile partition.
 #include <hip/hip_runtime.h>
 
