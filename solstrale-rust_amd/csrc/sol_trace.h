@@ -340,7 +340,21 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     }
     kind = SOL_REF_KIND(cur);
   }
-  if (cur == REF_DONE || kind == (BINARY ? SOL_REF_NODE : SOL_REF_WIDE)) { t.cur = cur; return; }
+  const bool is_inner = cur != REF_DONE && kind == (BINARY ? SOL_REF_NODE : SOL_REF_WIDE);
+#if SOL_PRIM_MIN > 1
+  // Postponed primitive tests (world search only): the lanes holding a primitive wait - keep it as their current reference -
+  // while fewer than SOL_PRIM_MIN of the wave's lanes do and some lane still has an inner node to visit next turn; the
+  // primitive part then runs with more lanes enabled. Results do not depend on the order of the tests.
+  unsigned long long inner_m = 0ull, prim_m = 0ull;
+  if (!BINARY) {
+    inner_m = __ballot(is_inner);
+    prim_m = __ballot(cur != REF_DONE && !is_inner);  // (counting per primitive kind instead was measured: no better)
+  }
+#endif
+  if (cur == REF_DONE || is_inner) { t.cur = cur; return; }
+#if SOL_PRIM_MIN > 1
+  if (!BINARY && inner_m != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) { t.cur = cur; return; }
+#endif
   const uint32_t idx = SOL_REF_INDEX(cur);
   if (kind == SOL_REF_TRIANGLE) {
     const float4* tp = reinterpret_cast<const float4*>(S.tris + idx);

@@ -7,6 +7,11 @@
 #define SOL_WG 256          // threads per workgroup = 4 wave64
 #define SOL_LDS_STACK 32    // traversal stack entries per lane kept in LDS (u32 each -> 32 KiB per workgroup)
 #define SOL_SPILL_STACK 480 // further entries per lane in a global spill area (deep trees, nested medium search)
+#ifndef SOL_PRIM_MIN
+#define SOL_PRIM_MIN 8      // trav_step: primitive tests wait until this many lanes of the wave hold one (1 = never wait).
+                            // MI355X, 1080p x 128 spp, C3 / C2 ms: 1: 199.8 / 128.4, 4: 196.6 / 126.5, 8: 193.1 / 122.5,
+                            // 12: 193.0 / 122.6, 16: 199.1 / 129.7, 24: 215.7 / 148.0
+#endif
 #define SOL_CHUNK 16        // samples per work item; fixed so that summation order never depends on the partition
 #define SOL_TILE 8          // 8x8-pixel blocks = one wave's worth of adjacent work items
 #define SOL_POOL_MAX 1024   // path slots per wave in the pool kernel (u16 queue entries: 2 KiB of LDS per wave)
@@ -22,8 +27,10 @@ struct __attribute__((aligned(16))) DNode {
 static_assert(sizeof(DNode) == 64, "DNode");
 
 // 96-byte 8-wide node with 8-bit quantised child boxes, built at upload from the binary tree (sol_api.cpp, WideBuilder).
-// One visit costs 6 dwordx4 accesses per lane for 8 children, against 4 per 2 children for DNode - and the kernel is bound
-// by the CU's divergent lane-access rate (TA/TD busy 80-99 %, profiles/r01_ta_td_counters.json). Child i's box is
+// One visit costs 6 dwordx4 accesses per lane for 8 children, against 4 per 2 children for DNode: a third of the dependent
+// memory round trips per ray (the binary-tree kernel was bound by the CU's divergent lane-access rate, TA/TD busy 80-99 %)
+// and fewer steps for the per-step costs of a divergent wave (narrower collapses were measured: 13.0 node visits per ray
+// on C3 at width 8, 14.9 at 6, 18.1 at 4, 34.5 at 2; each narrower tree is slower end to end). Child i's box is
 //   lo = origin + q_lo[i] * scale,  hi = origin + q_hi[i] * scale,  scale_axis = 2^(e_axis - 127)
 // and CONTAINS the child's padded fp32 box (the builder checks the decoded values), so it is a pure cull: results do not
 // depend on it. Children sit in the slot whose index bits (x<<2 | y<<1 | z) match their octant of the node, so that
