@@ -1,5 +1,6 @@
 """GPU bring-up script (not a pytest): renders a few scenes on cuda:0 through the C ABI, compares with the fp32 oracle,
 prints throughput. Usage: python tests/gpu_bringup.py [scene ...]"""
+import _paths  # noqa: F401  (sys.path)
 import sys
 import time
 

@@ -1,4 +1,5 @@
 """Feature isolation on the GPU: small scenes each exercising one feature, compared with the fp32 oracle."""
+import _paths  # noqa: F401  (sys.path)
 import numpy as np
 
 import parity_util as pu

@@ -1,5 +1,6 @@
 """Debug helper: renders one scene with two library builds (SOLSTRALE_BUILD_DIR A/B, separate processes), finds the pixels
 that differ and asks the fp32 oracle which build is right. Usage: python tests/gpu_diff.py <scene> <spp> <dirA> <dirB>"""
+import _paths  # noqa: F401  (sys.path)
 import os
 import subprocess
 import sys

@@ -1,5 +1,6 @@
 """Debug helper: full-frame comparison of one or more library builds against the fp32 oracle (cached).
 Usage: python tests/gpu_full_oracle.py <scene> <spp> <width> <height> <dir> [<dir> ...]   ('default' = _build)"""
+import _paths  # noqa: F401  (sys.path)
 import os
 import subprocess
 import sys

@@ -1,5 +1,6 @@
 """Debug helper: for given pixels of a scene, finds the sample indices whose GPU colour differs from the fp32 oracle.
 Usage: python tests/gpu_probe.py <scene> <n_samples> x,y [x,y ...]"""
+import _paths  # noqa: F401  (sys.path)
 import sys
 
 import numpy as np

@@ -1,5 +1,6 @@
 """Debug helper: prints the rays of one path on the GPU and in the fp32 oracle side by side.
 Usage: python tests/gpu_trace_case.py <scene> x,y,sample [x,y,sample ...]"""
+import _paths  # noqa: F401  (sys.path)
 import sys
 
 import numpy as np

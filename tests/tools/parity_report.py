@@ -1,7 +1,7 @@
 """Prints the parity figures of the BASELINE configs (GPU fp32 vs oracle fp32, fixed seed) as JSON lines (not a pytest)."""
+import _paths  # noqa: F401  (sys.path)
 import json
 
-import conftest  # noqa: F401  (sets sys.path as the test suite does)
 import orc
 import parity_util as pu
 from solstrale_amd import DeviceScene, RenderConfig, scenes

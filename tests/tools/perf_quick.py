@@ -1,6 +1,7 @@
 """Quick performance loop for kernel work (not a pytest): times the BASELINE-shaped workloads at reduced spp and prints a
 CRC of every image. The image is a pure function of (scene, seed), so a pure-performance change must keep every CRC.
-Usage: python tests/perf_quick.py [c1 c2 c3 test] [--spp N] [--phases]"""
+Usage: python tests/tools/perf_quick.py [c1 c2 c3 test] [--spp N] [--phases]"""
+import _paths  # noqa: F401  (sys.path)
 import sys
 import time
 import zlib

@@ -1,5 +1,5 @@
-"""Folds the rocprofv3 --pmc passes of tests/profile_round.sh into one JSON summary (not a pytest).
-Usage: python tests/pmc_summary.py gpurun_out/<tag>_pmc <kernel-name-substring> <samples-in-the-launch> > profiles/<tag>_pmc_summary.json
+"""Folds the rocprofv3 --pmc passes of tests/tools/profile_round.sh into one JSON summary (not a pytest).
+Usage: python tests/tools/pmc_summary.py gpurun_out/<tag>_pmc <kernel-name-substring> <samples-in-the-launch> > profiles/<tag>_pmc_summary.json
 
 Counters are summed over every dispatch whose kernel name contains the substring (bench.py --steps 1 --warmup 0 launches
 the uncounted render kernel exactly once). Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM):

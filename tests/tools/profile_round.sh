@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiling recipe of a round (run on the GPU box through gpurun, from the repo root):
-#   bash tests/profile_round.sh <tag>          -> gpurun_out/<tag>_{bench.json, bench_under_rocprof.json, kernel_stats.csv}
-#   bash tests/profile_round.sh <tag> pmc      -> gpurun_out/<tag>_pmc/<group>/... (one rocprofv3 --pmc pass per counter group)
+#   bash tests/tools/profile_round.sh <tag>          -> gpurun_out/<tag>_{bench.json, bench_under_rocprof.json, kernel_stats.csv}
+#   bash tests/tools/profile_round.sh <tag> pmc      -> gpurun_out/<tag>_pmc/<group>/... (one rocprofv3 --pmc pass per counter group)
 # The summaries are then copied into profiles/ (tracked).
 set -o pipefail
 tag=${1:-rXX}
