@@ -175,7 +175,7 @@ typedef struct SolSceneDesc {
 typedef struct SolStats {
   uint64_t samples;       /* ray_color(primary,0,0) evaluations                                         */
   uint64_t rays;          /* world closest-hit queries (src/renderer/mod.rs:165), any depth             */
-  uint64_t node_visits;   /* device BVH nodes fetched (64 B each)                                       */
+  uint64_t node_visits;   /* device BVH nodes fetched (sol_record_sizes: 96-B 8-wide nodes of the world)  */
   uint64_t sphere_tests, quad_tests, triangle_tests; /* primitive hit evaluations incl. light pdf tests */
   uint64_t shades;        /* material scatter evaluations                                               */
   uint64_t texel_fetches;
@@ -256,6 +256,23 @@ int sol_bloom_rgb8(SolScene* scene, const void* image_dev, uint32_t num_samples,
 int sol_gaussian_blur_weights(uint32_t kernel_size, double std_dev, double* out);
 
 int sol_stats(const SolScene* scene, SolStats* out);
+
+/* Diagnostic, host only (no device needed): builds the 8-wide quantised tree of the world exactly as sol_scene_create does
+ * (use_sah = 0: collapsed from the reference's topology, 1: from the binned-SAH rebuild) and verifies its structure with the
+ * device's decode arithmetic. Returns SOL_OK with the findings in `out`; the tree is sound iff box_violations ==
+ * leaf_mismatches == bad_empty_slots == 0. */
+typedef struct SolTreeCheck {
+  uint32_t n_wide;           /* wide nodes                                                                       */
+  uint32_t n_leaf_refs;      /* primitive references reachable from the root                                      */
+  uint32_t n_primitives;     /* primitive references of the reference-shaped tree (the multiset the tree must hold)*/
+  uint32_t depth;            /* levels of wide nodes                                                              */
+  uint32_t max_children;     /* most children in one node (<= 8)                                                  */
+  uint32_t box_violations;   /* children whose decoded box does not contain every padded primitive box below it   */
+  uint32_t leaf_mismatches;  /* primitive references missing from / surplus in the tree                           */
+  uint32_t bad_empty_slots;  /* empty slots that are not (NONE reference, inverted box)                           */
+  double inner_area, leaf_area; /* summed box areas of inner / primitive children (the surface-area cost estimate)  */
+} SolTreeCheck;
+int sol_world_tree_check(const SolSceneDesc* desc, int use_sah, SolTreeCheck* out);
 
 /* Diagnostic: traces the single path (pixel x, y counted from the image top; sample index) and writes 12 floats per ray
  * (origin xyz, direction xyz, hit t, hit reference bits, dfs index bits, depth, 0, 0), closed by a row holding the sample's

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <functional>
+#include <map>
 #include <vector>
 
 #include "../../include/solstrale_hip.h"
@@ -511,6 +513,78 @@ int sol_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) {
+  if (!d || !out) return fail(SOL_EINVAL, "null argument");
+  std::memset(out, 0, sizeof *out);
+  g_box_pad = box_pad_for(*d);
+  TreeBuilder tb(*d);
+  uint32_t root_ref;
+  Box root_box;
+  if (!tb.resolve(d->root, 0, root_ref, root_box)) return fail(SOL_EINVAL, "world: %s", tb.error.c_str());
+  if (SOL_REF_KIND(root_ref) != SOL_REF_NODE) return fail(SOL_EINVAL, "the world is a single primitive: no tree");
+  SahBuilder sah;
+  if (!sah.collect(tb.nodes, root_ref)) return fail(SOL_EINVAL, "the world's primitives cannot be collected (non-finite box or fewer than two)");
+  std::map<uint32_t, int> expected;  // primitive reference -> multiplicity
+  std::map<uint32_t, Box> prim_box;
+  for (const auto& p : sah.prims) { expected[p.ref]++; prim_box[p.ref] = p.box; }
+  out->n_primitives = (uint32_t)sah.prims.size();
+  uint32_t bin_root = root_ref;
+  if (use_sah) { Box b; bin_root = sah.build(0, sah.prims.size(), 0, b); }
+  WideBuilder wb(use_sah ? sah.nodes : tb.nodes);
+  const uint32_t wroot = wb.build(SOL_REF_INDEX(bin_root), 0);
+  out->n_wide = (uint32_t)wb.out.size();
+  out->depth = wb.max_depth;
+  out->inner_area = wb.inner_area; out->leaf_area = wb.leaf_area;
+  std::map<uint32_t, int> found;
+  // returns the union of the padded primitive boxes below `ref`
+  std::function<Box(uint32_t, uint32_t)> walk = [&](uint32_t ref, uint32_t depth) -> Box {
+    if (SOL_REF_KIND(ref) != SOL_REF_WIDE) {
+      found[ref]++;
+      out->n_leaf_refs++;
+      auto it = prim_box.find(ref);
+      return it == prim_box.end() ? empty_box() : it->second;
+    }
+    Box all = empty_box();
+    if (depth > 4096 || SOL_REF_INDEX(ref) >= wb.out.size()) { out->leaf_mismatches++; return all; }
+    const DWide& w = wb.out[SOL_REF_INDEX(ref)];
+    const float origin[3] = {w.ox, w.oy, w.oz};
+    float scale[3];
+    for (int a = 0; a < 3; ++a) { uint32_t bits = ((w.meta >> (8 * a)) & 0xFFu) << 23; std::memcpy(&scale[a], &bits, 4); }
+    uint32_t n_children = 0;
+    for (int s = 0; s < 8; ++s) {
+      uint32_t ql[3], qh[3];
+      for (int a = 0; a < 3; ++a) {
+        ql[a] = (w.q[2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xFFu;
+        qh[a] = (w.q[6 + 2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xFFu;
+      }
+      if (SOL_REF_KIND(w.ref[s]) == SOL_REF_NONE) {
+        if (!(ql[0] == 255u && qh[0] == 0u && ql[1] == 255u && qh[1] == 0u && ql[2] == 255u && qh[2] == 0u)) out->bad_empty_slots++;
+        continue;
+      }
+      n_children++;
+      const Box below = walk(w.ref[s], depth + 1);
+      bool ok = true;
+      for (int a = 0; a < 3; ++a) {
+        const float lo = WideBuilder::decode(origin[a], ql[a], scale[a]), hi = WideBuilder::decode(origin[a], qh[a], scale[a]);
+        if (below.v[2 * a] <= below.v[2 * a + 1] && !(lo <= below.v[2 * a] && hi >= below.v[2 * a + 1])) ok = false;
+      }
+      if (!ok) out->box_violations++;
+      SahBuilder::grow(all, below);
+    }
+    if (n_children > out->max_children) out->max_children = n_children;
+    return all;
+  };
+  walk(wroot, 0);
+  for (const auto& e : expected) {
+    auto it = found.find(e.first);
+    const int f = it == found.end() ? 0 : it->second;
+    if (f != e.second) out->leaf_mismatches += (uint32_t)std::abs(f - e.second);
+  }
+  for (const auto& f : found)
+    if (!expected.count(f.first)) out->leaf_mismatches += (uint32_t)f.second;
+  return SOL_OK;
 }
 
 int sol_record_sizes(uint32_t out[6]) {

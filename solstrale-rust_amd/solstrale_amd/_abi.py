@@ -124,6 +124,15 @@ def _sig(lib, name, res, args):
     return f
 
 
+class SolTreeCheck(C.Structure):
+    _fields_ = [("n_wide", C.c_uint32), ("n_leaf_refs", C.c_uint32), ("n_primitives", C.c_uint32), ("depth", C.c_uint32),
+                ("max_children", C.c_uint32), ("box_violations", C.c_uint32), ("leaf_mismatches", C.c_uint32),
+                ("bad_empty_slots", C.c_uint32), ("inner_area", C.c_double), ("leaf_area", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 def load_hip():
     """Loads libsolstrale_hip.so (the product). Fails loudly if it has not been built."""
     if "hip" in _libs:
@@ -152,6 +161,7 @@ def load_hip():
     _sig(lib, "sol_bloom_rgb8", C.c_int, [P, C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_uint8)])
     _sig(lib, "sol_gaussian_blur_weights", C.c_int, [C.c_uint32, C.c_double, C.POINTER(C.c_double)])
     _sig(lib, "sol_stats", C.c_int, [P, C.POINTER(SolStats)])
+    _sig(lib, "sol_world_tree_check", C.c_int, [C.c_void_p, C.c_int, C.POINTER(SolTreeCheck)])
     _sig(lib, "sol_record_sizes", C.c_int, [C.POINTER(C.c_uint32)])
     _sig(lib, "sol_last_error", C.c_char_p, [])
     _sig(lib, "sol_debug_path", C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32])
@@ -166,7 +176,7 @@ HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol
                "sol_accum_floats", "sol_accum_ptr", "sol_scene_bind_accum", "sol_scene_set_stream", "sol_clear",
                "sol_render", "sol_render_counted", "sol_sync", "sol_read", "sol_unpermute", "sol_tonemap_rgb8",
                "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms",
-               "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights"]
+               "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check"]
 
 
 def load_host():

@@ -35,6 +35,16 @@ def eval_functions(fn, rows, out_cols, device=0):
     return out
 
 
+def world_tree_check(scene, use_sah):
+    """Host-only structural check of the 8-wide tree sol_scene_create would build for `scene` (no device needed)."""
+    lib = _abi.load_hip()
+    out = _abi.SolTreeCheck()
+    rc = lib.sol_world_tree_check(scene.desc_ptr, 1 if use_sah else 0, C.byref(out))
+    if rc != 0:
+        raise DeviceError(rc, lib.sol_last_error().decode())
+    return out.as_dict()
+
+
 class DeviceScene:
     """sol_scene_create .. sol_scene_destroy"""
 

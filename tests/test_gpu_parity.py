@@ -246,6 +246,14 @@ def test_deep_tree_uses_the_spill_stack(bvh, monkeypatch):
         assert st["max_stack"] > 32, st  # the spill area was really used
 
 
+def test_degenerate_world_parity():
+    """Coincident primitives, dust of 1e-4 spheres and a 5e3 sphere around everything (tests/test_world_tree.py checks the tree's
+    structure on the CPU): quantisation grids spanning 8 orders of magnitude must still return the oracle's hits."""
+    import test_world_tree as twt
+    sc = twt._flat_and_huge()
+    assert_parity(sc, 8)
+
+
 def test_errors_are_codes_not_crashes():
     sc = scenes.cornell_box(RenderConfig(16, 16, 1))
     with DeviceScene(sc) as ds:

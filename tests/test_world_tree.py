@@ -1,0 +1,76 @@
+"""Host-only structure checks of the device's world tree (sol_world_tree_check): the 8-wide quantised tree that
+sol_scene_create builds - from the reference's topology and from the binned-SAH rebuild - must hold every primitive reference of
+the reference-shaped tree exactly once, and every child's DECODED box (the device's arithmetic) must contain all padded
+primitive boxes below it. That is the whole correctness argument of the wide tree ("tree independence"); the GPU
+suite then shows the images agree bit for bit."""
+import numpy as np
+import pytest
+
+from solstrale_amd import CameraConfig, DeviceError, RenderConfig, SceneBuilder, scenes, world_tree_check
+
+RC = RenderConfig(64, 64, 1)
+
+
+def _chain(depth=48):
+    b = SceneBuilder()
+    m = b.Lambertian(b.SolidColor(.8, .8, .8))
+    ids = [b.Sphere((float(x), 0.3 * (x % 3), 0.), 0.45, m) for x in range(depth + 2)]
+    inner = b.Bvh(ids[:2])
+    for k in range(2, depth + 2):
+        inner = b.Bvh([inner, ids[k]]) if k % 2 else b.Bvh([ids[k], inner])
+    light = b.Sphere((0., 1e4, 0.), 3e3, b.DiffuseLight(3, 3, 3))
+    return b.finish(b.Bvh([inner, light]), CameraConfig(12., 0., (-30., 0.4, 0.3), (50., 0.3, 0.), (0, 1, 0)), (.1, .1, .1), RC)
+
+
+def _flat_and_huge():
+    """Degenerate inputs: coincident centroids, flat boxes, a huge primitive among tiny ones."""
+    b = SceneBuilder()
+    m = b.Lambertian(b.SolidColor(.5, .5, .5))
+    world = [b.Quad((0., 0., 0.), (1., 0., 0.), (0., 1., 0.), m) for _ in range(9)]          # nine identical quads
+    world += [b.Sphere((1e-3 * i, 0., 5.), 1e-4, m) for i in range(40)]                         # dust
+    world.append(b.Sphere((0., 0., 0.), 5e3, m))                                                 # a huge sphere around all
+    world.append(b.Quad((-1., 9., -1.), (2., 0., 0.), (0., 0., 2.), b.DiffuseLight(5, 5, 5)))
+    return b.finish(b.Bvh(world), CameraConfig(40., 0., (0., 1., -8.), (0., 0., 0.), (0, 1, 0)), (0., 0., 0.), RC)
+
+
+SCENES = {
+    "cornell": lambda: scenes.cornell_box(RC),
+    "spheres_2000": lambda: scenes.cornell_spheres(RC, n_spheres=2000),
+    "atrium_30k": lambda: scenes.sponza_like(RC, n_triangles=30001, texture_size=16),
+    "statue_40k": lambda: scenes.statue_like(RC, n_triangles=40000),
+    "reference_test_scene": lambda: scenes.create_test_scene(RC),
+    "spider_obj": lambda: scenes.create_obj_scene(RC),
+    "chain_48": _chain,
+    "degenerate": _flat_and_huge,
+}
+
+
+@pytest.mark.parametrize("use_sah", [False, True], ids=["reference_topology", "sah"])
+@pytest.mark.parametrize("name", list(SCENES))
+def test_wide_tree_is_sound(name, use_sah):
+    sc = SCENES[name]()
+    r = world_tree_check(sc, use_sah)
+    assert r["box_violations"] == 0 and r["leaf_mismatches"] == 0 and r["bad_empty_slots"] == 0, r
+    assert r["n_leaf_refs"] == r["n_primitives"] >= 2
+    assert 1 <= r["max_children"] <= 8 and r["depth"] >= 1
+    # a collapsed tree needs far fewer nodes than the n - 1 of the binary tree (at most ~n/2 even for a chain)
+    assert r["n_wide"] <= max(1, (r["n_primitives"] + 1) // 2)
+    assert np.isfinite(r["inner_area"]) and np.isfinite(r["leaf_area"])
+
+
+def test_sah_rebalances_a_chain_and_keeps_good_trees_good():
+    ref, sah = world_tree_check(_chain(), False), world_tree_check(_chain(), True)
+    assert ref["depth"] >= 7 and sah["depth"] <= 4  # 50 spheres: a chain collapses to >= 49/7 levels, SAH to ~log8
+    for name in ("atrium_30k", "statue_40k"):
+        sc = SCENES[name]()
+        ref, sah = world_tree_check(sc, False), world_tree_check(sc, True)
+        cost = lambda r: 2.5 * r["inner_area"] + r["leaf_area"]
+        assert cost(sah) < 1.1 * cost(ref), (name, cost(ref), cost(sah))
+
+
+def test_single_primitive_world_has_no_tree():
+    b = SceneBuilder()
+    light = b.Sphere((0., 0., 0.), 1., b.DiffuseLight(1, 1, 1))
+    sc = b.finish(light, CameraConfig(40., 0., (0., 0., 5.), (0., 0., 0.), (0, 1, 0)), (0., 0., 0.), RC)
+    with pytest.raises(DeviceError):
+        world_tree_check(sc, True)
