@@ -936,6 +936,7 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
   // occupancy (0.45 -> 0.67-0.73) but pay for it in state traffic, refill stalls and per-round tails, so v1 is the default.
   if (version == 0) version = 1;
   int bpc = version == 3 ? sol_wf_trace_blocks_per_cu(count, s->has_medium) : sol_render_blocks_per_cu(version, count, s->has_medium);
+  if (const char* mb = std::getenv("SOL_MAX_BPC")) bpc = std::max(1, std::min(bpc, std::atoi(mb)));  // occupancy experiments
   uint32_t grid = (uint32_t)(s->n_cu * bpc);
   const uint32_t need_blocks = (P.n_items + SOL_WG - 1) / SOL_WG;
   if (grid > need_blocks) grid = need_blocks;

@@ -25,7 +25,7 @@
 // v1: one path per lane
 // ---------------------------------------------------------------------------------------------------------------------------
 template <bool COUNT, bool MEDIUM>
-__global__ void __launch_bounds__(SOL_WG, 4)  // 4 waves per SIMD: the 32 KiB LDS stack allows 5 workgroups per CU, 128 VGPRs 4
+__global__ void __launch_bounds__(SOL_WG, SOL_V1_MIN_WAVES)  // 4 waves per SIMD: the 32 KiB LDS stack allows 5 workgroups per CU, 128 VGPRs 4
 sol_render_kernel(const DevScene S, const RenderParams P, float* __restrict__ acc, float* __restrict__ partial,
                   uint32_t* __restrict__ work_counter, uint32_t* __restrict__ spill, DevCounters* __restrict__ dcnt) {
   __shared__ uint32_t lds_stack[SOL_LDS_STACK * SOL_WG];

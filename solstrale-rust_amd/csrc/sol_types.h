@@ -5,7 +5,15 @@
 #include <stdint.h>
 
 #define SOL_WG 256          // threads per workgroup = 4 wave64
+#ifndef SOL_LDS_STACK
 #define SOL_LDS_STACK 32    // traversal stack entries per lane kept in LDS (u32 each -> 32 KiB per workgroup)
+#endif
+#ifndef SOL_V1_MIN_WAVES
+#define SOL_V1_MIN_WAVES 4  // waves per SIMD the one-path-per-lane kernel is compiled for (register budget 512 / waves).
+                            // Throughput still grows with residency (C3, SOL_MAX_BPC: 1 wave 492, 2: 862, 3: 1141, 4: 1347
+                            // Msamples/s), but 5 and 6 waves (with a 24-entry LDS stack) need 96 / 80 VGPRs and the 58 / 95
+                            // spilled registers cost what the residency buys (1351 / 1375 on C3, C2 slower).
+#endif
 #define SOL_SPILL_STACK 480 // further entries per lane in a global spill area (deep trees, nested medium search)
 #ifndef SOL_PRIM_MIN
 #define SOL_PRIM_MIN 8      // trav_step: primitive tests wait until this many lanes of the wave hold one (1 = never wait).
