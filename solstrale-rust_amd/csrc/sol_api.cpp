@@ -832,10 +832,9 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
     if (kv[0] == 'v') kv++;
     s->kernel_version = (kv[0] >= '1' && kv[0] <= '3') ? kv[0] - '0' : 0;
   }
-  // v1's search/shade switch (RenderParams::switch_below), measured on MI355X at 1080p: 16/64 is the best common setting
-  // for worlds with a real tree (C3 127 -> 107 ms, C2 100 -> 78 ms per 64 spp); a world of a few wide nodes (the Cornell box:
-  // 1.3 node visits per ray) has no search imbalance to hide, and shading finished lanes early only dilutes the shading.
-  s->switch_below = wb->out.size() > 8 ? 16u : 0u;
+  // v1's search/shade switch (RenderParams::switch_below), measured on MI355X at 1080p x 128 spp (ms, C1 / C2 / C3 / test scene):
+  // 0: 29.2 / 162.9 / 236.7 / 25.9, 8: 27.7 / 124.3 / 193.1 / 25.5, 16: 27.5 / 111.8 / 186.9 / 25.6, 24: 28.6 / 108.6 / 192.3 / 26.8.
+  s->switch_below = 16u;
   if (const char* ps = std::getenv("SOL_SWITCH")) s->switch_below = (uint32_t)std::min(64, std::max(0, std::atoi(ps)));
   if (const char* ps = std::getenv("SOL_POOL_SLOTS")) s->pool_slots_override = (uint32_t)std::atoi(ps);
   if (const char* ps = std::getenv("SOL_WF_SLOTS")) s->wf_slots = std::max(4096, std::atoi(ps));
@@ -868,7 +867,6 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
     hipFree(cand[1 - pick].w);
     s->wides = cand[pick].w;
     S.wides = s->wides; S.wroot = cand[pick].root; s->tree_depth = cand[pick].depth;
-    if (!std::getenv("SOL_SWITCH")) s->switch_below = cand[pick].b->out.size() > 8 ? 16u : 0u;
     s->stats = SolStats{};
     if (rc || (rc = set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));

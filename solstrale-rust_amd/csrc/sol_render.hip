@@ -47,6 +47,8 @@ sol_render_kernel(const DevScene S, const RenderParams P, float* __restrict__ ac
   Path p = {};
   Trav t;
   t.cur = REF_DONE;
+  __shared__ uint32_t reservoir[SOL_WG / 64][2];  // per wave: next reserved item, end of the reservation
+  if (lane == 0) { reservoir[tid >> 6][0] = 0u; reservoir[tid >> 6][1] = 0u; }
 
   for (;;) {
     // ---- lanes whose search is over: shade the vertex, then start the next ray of the path / sample / item ----
@@ -66,14 +68,26 @@ sol_render_kernel(const DevScene S, const RenderParams P, float* __restrict__ ac
           }
         }
       }
-      // work fetch: one atomic per wave, lanes take consecutive items (an aligned wave = one 8x8 pixel block)
+      // work fetch. The wave keeps a reservoir [next, end) of reserved items in LDS and refills it 64 items at a time (one
+      // aligned 8x8 pixel block of one chunk) with ONE returning atomic; lanes take consecutive items from it by popcount
+      // prefix. The wave thus waits for the global counter (1-3 us under load, ~88 dequeues/us per address) once per 64
+      // items instead of once per service pass.
       if (!have_item) {
         const unsigned long long need = __ballot(1);
         const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(work_counter, (uint32_t)__popcll(need));
-        base = __shfl(base, (int)leader);
-        const uint32_t item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+        const uint32_t n_need = (uint32_t)__popcll(need), my = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+        uint32_t* res = reservoir[tid >> 6];
+        const uint32_t next = res[0], left = res[1] - next;  // (same wave wrote them: program order)
+        uint32_t fresh = 0;
+        if (n_need > left) {  // take what is left, then continue in a fresh block of 64
+          if (lane == leader) fresh = atomicAdd(work_counter, 64u);
+          fresh = __shfl(fresh, (int)leader);
+        }
+        if (lane == leader) {
+          res[0] = n_need > left ? fresh + (n_need - left) : next + n_need;
+          if (n_need > left) res[1] = fresh + 64u;
+        }
+        const uint32_t item = my < left ? next + my : fresh + (my - left);
         if (item >= P.n_items) break;  // no work left for this lane
         if (!decode_item(S, P, item, it)) continue;
         s = P.first_sample + it.chunk * SOL_CHUNK;
