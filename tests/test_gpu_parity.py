@@ -246,6 +246,16 @@ def test_deep_tree_uses_the_spill_stack(bvh, monkeypatch):
         assert st["max_stack"] > 32, st  # the spill area was really used
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_scenes_parity(seed):
+    """Randomised coverage: every primitive, material (nested Blend, normal maps, image textures), transformation chain, nested
+    Bvh, constant medium and light shape in seeded random small scenes; every pixel must match the fp32 oracle."""
+    import random_scenes
+    sc = random_scenes.random_scene(seed)
+    res = assert_parity(sc, 4, max_bad=1)  # one pixel of slack per scene for fp32 branch flips the contract cannot exclude
+    assert res["pixels"] == 40 * 32
+
+
 def test_degenerate_world_parity():
     """Coincident primitives, dust of 1e-4 spheres and a 5e3 sphere around everything (tests/test_world_tree.py checks the tree's
     structure on the CPU): quantisation grids spanning 8 orders of magnitude must still return the oracle's hits."""

@@ -74,3 +74,13 @@ def test_single_primitive_world_has_no_tree():
     sc = b.finish(light, CameraConfig(40., 0., (0., 0., 5.), (0., 0., 0.), (0, 1, 0)), (0., 0., 0.), RC)
     with pytest.raises(DeviceError):
         world_tree_check(sc, True)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_build_sound_trees(seed):
+    import random_scenes
+    sc = random_scenes.random_scene(seed)
+    for use_sah in (False, True):
+        r = world_tree_check(sc, use_sah)
+        assert r["box_violations"] == 0 and r["leaf_mismatches"] == 0 and r["bad_empty_slots"] == 0, (seed, use_sah, r)
+        assert r["n_leaf_refs"] == r["n_primitives"]
