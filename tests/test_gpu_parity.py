@@ -252,7 +252,7 @@ def test_random_scenes_parity(seed):
     Bvh, constant medium and light shape in seeded random small scenes; every pixel must match the fp32 oracle."""
     import random_scenes
     sc = random_scenes.random_scene(seed)
-    res = assert_parity(sc, 4, max_bad=1)  # one pixel of slack per scene for fp32 branch flips the contract cannot exclude
+    res = assert_parity(sc, 4)  # (tests/tools/random_parity_sweep.py ran seeds 100-1599 on MI355X: no pixel over 1e-5)
     assert res["pixels"] == 40 * 32
 
 
