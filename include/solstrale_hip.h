@@ -258,7 +258,7 @@ int sol_gaussian_blur_weights(uint32_t kernel_size, double std_dev, double* out)
 int sol_stats(const SolScene* scene, SolStats* out);
 
 /* Diagnostic, host only (no device needed): builds the 8-wide quantised tree of the world exactly as sol_scene_create does
- * (use_sah = 0: collapsed from the reference's topology, 1: from the binned-SAH rebuild) and verifies its structure with the
+ * (use_sah = 0: collapsed from the reference's topology, 1: from the 16-bin SAH rebuild, n > 1: from the n-bin rebuild) and verifies its structure with the
  * device's decode arithmetic. Returns SOL_OK with the findings in `out`; the tree is sound iff box_violations ==
  * leaf_mismatches == bad_empty_slots == 0. */
 typedef struct SolTreeCheck {

@@ -13,6 +13,7 @@
 #include <string>
 #include <functional>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "../../include/solstrale_hip.h"
@@ -334,7 +335,8 @@ struct SahBuilder {
   struct Prim { uint32_t ref; Box box; float c[3]; };
   std::vector<Prim> prims;
   std::vector<DNode> nodes;
-  static constexpr int BINS = 16;
+  static constexpr int MAX_BINS = 64;
+  int BINS = 16;
 
   // Leaves of the reference-shaped device tree under `root` (a shared sub-tree contributes its leaves once per use).
   bool collect(const std::vector<DNode>& bin, uint32_t root) {
@@ -383,16 +385,16 @@ struct SahBuilder {
         const float ext = cmax[a] - cmin[a];
         if (!(ext > 0.f)) continue;
         const float k = (float)BINS / ext;
-        Box bb[BINS];
-        uint32_t bn[BINS];
+        Box bb[MAX_BINS];
+        uint32_t bn[MAX_BINS];
         for (int b = 0; b < BINS; ++b) { bb[b] = empty_box(); bn[b] = 0; }
         for (size_t i = lo; i < hi; ++i) {
           int b = std::min(BINS - 1, std::max(0, (int)((prims[i].c[a] - cmin[a]) * k)));
           grow(bb[b], prims[i].box);
           bn[b]++;
         }
-        double ra[BINS];
-        uint32_t rn[BINS];
+        double ra[MAX_BINS];
+        uint32_t rn[MAX_BINS];
         Box acc = empty_box();
         uint32_t n = 0;
         for (int b = BINS - 1; b > 0; --b) { grow(acc, bb[b]); n += bn[b]; ra[b] = area(acc); rn[b] = n; }
@@ -531,7 +533,7 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
   for (const auto& p : sah.prims) { expected[p.ref]++; prim_box[p.ref] = p.box; }
   out->n_primitives = (uint32_t)sah.prims.size();
   uint32_t bin_root = root_ref;
-  if (use_sah) { Box b; bin_root = sah.build(0, sah.prims.size(), 0, b); }
+  if (use_sah) { Box b; sah.BINS = use_sah > 1 ? std::min((int)SahBuilder::MAX_BINS, use_sah) : 16; bin_root = sah.build(0, sah.prims.size(), 0, b); }
   WideBuilder wb(use_sah ? sah.nodes : tb.nodes);
   const uint32_t wroot = wb.build(SOL_REF_INDEX(bin_root), 0);
   out->n_wide = (uint32_t)wb.out.size();
@@ -746,36 +748,70 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
       if (SOL_REF_KIND(r) == SOL_REF_NODE) { stk.push_back(tb.nodes[SOL_REF_INDEX(r)].left); stk.push_back(tb.nodes[SOL_REF_INDEX(r)].right); }
     }
   }
-  // 8-wide tree of the world (a visit may push up to 7 children)
-  // over the SAH rebuild of the world's tree (SOL_BVH=ref keeps the reference's topology: A/B runs, deep-tree tests)
-  const char* bvh_env = std::getenv("SOL_BVH");
-  SahBuilder sah;
-  uint32_t sah_root = SOL_MAKE_REF(SOL_REF_NONE, 0);
-  if (!(bvh_env && std::strcmp(bvh_env, "ref") == 0) && SOL_REF_KIND(root_ref) == SOL_REF_NODE && sah.collect(tb.nodes, root_ref)) {
-    Box b;
-    sah_root = sah.build(0, sah.prims.size(), 0, b);
-  }
-  WideBuilder wb_sah(sah.nodes), wb_ref(tb.nodes);
-  bool use_sah = false, calibrate = false;
-  uint32_t wroot = root_ref, wroot_ref = root_ref, wroot_sah = root_ref;
-  if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) wroot_ref = wb_ref.build(SOL_REF_INDEX(root_ref), 0);
+  // 8-wide tree of the world (a visit may push up to 7 children). Candidates: the reference's topology collapsed, and
+  // binned-SAH rebuilds over the same primitives with 8, 16 and 64 bins (how well the binary splits line up with the 8-wide
+  // collapse varies with the bin count: C2 visits 9.8 / 12.2 / 11.4 nodes per ray at 8 / 16 / 64 bins, 11.2 on the
+  // reference's topology; C3 13.3 / 13.0 / 12.9 vs 14.4). A counted probe render on the device picks one (below).
+  // SOL_BVH=ref | sah (16 bins) | sah8 | sah16 | sah64 forces a candidate (A/B runs, deep-tree tests).
+  struct TreeCand {
+    std::string name;
+    std::unique_ptr<SahBuilder> sah;
+    std::unique_ptr<WideBuilder> wb;
+    uint32_t wroot = 0, depth = 0;
+    DWide* dev = nullptr;
+    double cost = 0.;
+  };
+  std::vector<TreeCand> cands;
   auto depth_of = [&](const WideBuilder& w) { return (SOL_WORLD_BINARY ? world_depth : 7u * w.max_depth) + medium_depth + 2; };
   const uint32_t stack_limit = SOL_LDS_STACK + SOL_SPILL_STACK;
-  if (SOL_REF_KIND(sah_root) == SOL_REF_NODE) {
-    wroot_sah = wb_sah.build(SOL_REF_INDEX(sah_root), 0);
-    const bool sah_ok = depth_of(wb_sah) <= stack_limit, ref_ok = depth_of(wb_ref) <= stack_limit;
-    if (sah_ok && (!ref_ok || (bvh_env && std::strcmp(bvh_env, "sah") == 0))) use_sah = true;
-    else if (sah_ok && !bvh_env) {
-      // Both usable: the surface-area estimate decides for now, a counted probe render on the device decides below (the
-      // estimate knows nothing of occlusion and visit order: it prefers the SAH tree for C2, which measures 10% slower).
-      use_sah = wb_sah.cost() < wb_ref.cost();
-      calibrate = !SOL_WORLD_BINARY;
+  const char* bvh_env = std::getenv("SOL_BVH");
+  const std::string want = bvh_env ? (std::strcmp(bvh_env, "sah") == 0 ? "sah16" : bvh_env) : "";
+  uint32_t wroot = root_ref;
+  if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) {
+    {
+      TreeCand c;
+      c.name = "ref";
+      c.wb.reset(new WideBuilder(tb.nodes));
+      c.wroot = c.wb->build(SOL_REF_INDEX(root_ref), 0);
+      c.depth = depth_of(*c.wb);
+      cands.push_back(std::move(c));
     }
+    for (int bins : {8, 16, 64}) {
+      const std::string name = "sah" + std::to_string(bins);
+      if (want == "ref" || (!want.empty() && want != name)) continue;
+      TreeCand c;
+      c.name = name;
+      c.sah.reset(new SahBuilder());
+      c.sah->BINS = bins;
+      if (!c.sah->collect(tb.nodes, root_ref)) break;  // non-finite boxes or a single primitive: reference topology only
+      Box bx;
+      const uint32_t r = c.sah->build(0, c.sah->prims.size(), 0, bx);
+      c.wb.reset(new WideBuilder(c.sah->nodes));
+      c.wroot = c.wb->build(SOL_REF_INDEX(r), 0);
+      c.depth = depth_of(*c.wb);
+      cands.push_back(std::move(c));
+    }
+    // drop what cannot run; a forced choice drops the rest
+    std::vector<TreeCand> keep;
+    for (auto& c : cands)
+      if (c.depth <= stack_limit && (want.empty() || c.name == want || (want != "ref" && c.name == "ref" && cands.size() == 1))) keep.push_back(std::move(c));
+    if (keep.empty()) {
+      uint32_t dmin = 0xFFFFFFFFu;
+      for (auto& c : cands) dmin = std::min(dmin, c.depth);
+      return fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", dmin, stack_limit);
+    }
+    cands = std::move(keep);
+    // provisional choice by the surface-area estimate (it knows nothing of occlusion and visit order: the probe decides)
+    size_t best = 0;
+    for (size_t i = 1; i < cands.size(); ++i)
+      if (cands[i].wb->cost() < cands[best].wb->cost()) best = i;
+    std::swap(cands[0], cands[best]);
+    wroot = cands[0].wroot;
   }
-  wroot = use_sah ? wroot_sah : wroot_ref;
-  WideBuilder* wb = use_sah ? &wb_sah : &wb_ref;
-  uint32_t tree_depth = depth_of(*wb);
-  if (tree_depth > stack_limit) return fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", tree_depth, stack_limit);
+  const bool calibrate = cands.size() > 1 && !SOL_WORLD_BINARY;
+  static const std::vector<DWide> no_wides;
+  const std::vector<DWide>& wides0 = cands.empty() ? no_wides : cands[0].wb->out;
+  uint32_t tree_depth = cands.empty() ? medium_depth + 2 : cands[0].depth;
 
   // ---- lights ----
   std::vector<uint32_t> lights(d->lights, d->lights + d->n_lights);
@@ -799,7 +835,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   s->stream = s->own_stream;
   int rc;
-  if ((rc = upload(tb.nodes, &s->nodes)) || (rc = upload(wb->out, &s->wides)) || (rc = upload(tris, &s->tris)) || (rc = upload(tshade, &s->tri_shade)) ||
+  if ((rc = upload(tb.nodes, &s->nodes)) || (rc = upload(wides0, &s->wides)) || (rc = upload(tris, &s->tris)) || (rc = upload(tshade, &s->tri_shade)) ||
       (rc = upload(quads, &s->quads)) || (rc = upload(spheres, &s->spheres)) || (rc = upload(mediums, &s->mediums)) ||
       (rc = upload(mats, &s->mats)) || (rc = upload(texs, &s->texs)) || (rc = upload(lights, &s->lights)))
     return rc;
@@ -845,28 +881,30 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   s->blocks_y = (d->height + SOL_TILE - 1) / SOL_TILE;
   if ((rc = set_partition(s, 0, 1))) return rc;
   if (calibrate) {
-    // Probe both world trees with a counted render of 16 samples per pixel over ~256 pixel blocks spread across the image and
-    // keep the one with less search work (a wide-node visit weighs ~2.5 primitive tests, by instruction count). Images do
-    // not depend on the tree, the counters are deterministic, so is the choice.
-    DWide* other = nullptr;
-    WideBuilder* wo = use_sah ? &wb_ref : &wb_sah;
-    if ((rc = upload(wo->out, &other))) return rc;
-    struct Cand { DWide* w; uint32_t root; uint32_t depth; WideBuilder* b; double cost; } cand[2] = {
-        {s->wides, wroot, tree_depth, wb, 0.}, {other, use_sah ? wroot_ref : wroot_sah, depth_of(*wo), wo, 0.}};
+    // Probe every candidate tree with a counted render of 16 samples per pixel over ~256 pixel blocks spread across the image
+    // and keep the one with the least search work (a wide-node visit weighs ~2.5 primitive tests, by instruction count).
+    // Images do not depend on the tree, the counters are deterministic, so is the choice.
+    cands[0].dev = s->wides;
+    for (size_t k = 1; k < cands.size(); ++k)
+      if ((rc = upload(cands[k].wb->out, &cands[k].dev))) return rc;
     const uint32_t nb = s->blocks_x * s->blocks_y;
     rc = set_partition(s, 0, (int)std::max(1u, nb / 256u));
-    for (int k = 0; k < 2 && !rc; ++k) {
-      S.wides = cand[k].w; S.wroot = cand[k].root; s->tree_depth = cand[k].depth;
+    size_t pick = 0;
+    for (size_t k = 0; k < cands.size() && !rc; ++k) {
+      S.wides = cands[k].dev; S.wroot = cands[k].wroot; s->tree_depth = cands[k].depth;
       if (!(rc = sol_clear(s)) && !(rc = render_probe(s)))
-        cand[k].cost = 2.5 * (double)s->stats.node_visits + (double)(s->stats.sphere_tests + s->stats.quad_tests + s->stats.triangle_tests);
+        cands[k].cost = 2.5 * (double)s->stats.node_visits + (double)(s->stats.sphere_tests + s->stats.quad_tests + s->stats.triangle_tests);
+      if (!rc && cands[k].cost < cands[pick].cost) pick = k;
     }
-    const int pick = (!rc && cand[1].cost < cand[0].cost) ? 1 : 0;
-    if (std::getenv("SOL_VERBOSE"))
-      std::fprintf(stderr, "[solstrale] world tree probe: %s cost %.4g, %s cost %.4g -> %s\n", use_sah ? "SAH" : "reference", cand[0].cost,
-                   use_sah ? "reference" : "SAH", cand[1].cost, (pick == 0) == use_sah ? "SAH" : "reference");
-    hipFree(cand[1 - pick].w);
-    s->wides = cand[pick].w;
-    S.wides = s->wides; S.wroot = cand[pick].root; s->tree_depth = cand[pick].depth;
+    if (std::getenv("SOL_VERBOSE")) {
+      std::fprintf(stderr, "[solstrale] world tree probe:");
+      for (auto& c : cands) std::fprintf(stderr, " %s %.4g (%zu nodes)", c.name.c_str(), c.cost, c.wb->out.size());
+      std::fprintf(stderr, " -> %s\n", cands[pick].name.c_str());
+    }
+    for (size_t k = 0; k < cands.size(); ++k)
+      if (k != pick) hipFree(cands[k].dev);
+    s->wides = cands[pick].dev;
+    S.wides = s->wides; S.wroot = cands[pick].wroot; s->tree_depth = cands[pick].depth;
     s->stats = SolStats{};
     if (rc || (rc = set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));

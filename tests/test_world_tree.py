@@ -45,7 +45,7 @@ SCENES = {
 }
 
 
-@pytest.mark.parametrize("use_sah", [False, True], ids=["reference_topology", "sah"])
+@pytest.mark.parametrize("use_sah", [0, 8, 16, 64], ids=["reference_topology", "sah8", "sah16", "sah64"])
 @pytest.mark.parametrize("name", list(SCENES))
 def test_wide_tree_is_sound(name, use_sah):
     sc = SCENES[name]()
@@ -80,7 +80,7 @@ def test_single_primitive_world_has_no_tree():
 def test_random_scenes_build_sound_trees(seed):
     import random_scenes
     sc = random_scenes.random_scene(seed)
-    for use_sah in (False, True):
+    for use_sah in (0, 8, 16, 64):
         r = world_tree_check(sc, use_sah)
         assert r["box_violations"] == 0 and r["leaf_mismatches"] == 0 and r["bad_empty_slots"] == 0, (seed, use_sah, r)
         assert r["n_leaf_refs"] == r["n_primitives"]
