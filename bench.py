@@ -59,6 +59,10 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N>1 dry run on a box with ONE GPU: every rank uses cuda:0, the gather goes through gloo on host "
+                         "copies (RCCL refuses two ranks on one device); exercises partition, gather protocol and un-permute, "
+                         "its throughput means nothing and the JSON line says so")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,10 +76,15 @@ def main():
     if rank == 0:
         __graft_entry__.build()
     import torch.distributed as dist
+    if args.rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist.barrier()
     if rank != 0:
         __graft_entry__.build()  # no-op when up to date; loads the libraries
@@ -131,7 +140,12 @@ def main():
             n = min(spp - f, max_spp_call)
             ds.render(f, n, SEED)
             f += n
-        gathered = tiles.gather_to_rank0(acc, world, rank)
+        if args.rehearse and world > 1:
+            torch.cuda.synchronize(dev)
+            g = tiles.gather_to_rank0(acc.cpu(), world, rank)
+            gathered = g.to(dev) if rank == 0 else None
+        else:
+            gathered = tiles.gather_to_rank0(acc, world, rank)
         if rank == 0:
             ds.unpermute(gathered.data_ptr(), world, image.data_ptr())
 
@@ -148,7 +162,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -176,7 +190,10 @@ def main():
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(args.workload)
+                tj = json.load(open(tf))
+                # measured L2<->fabric bytes per sample (profiles/, separate rocprofv3 --pmc passes) x this launch's samples
+                if args.workload == "c3" and "_bytes_per_sample" in tj:
+                    traffic = int(tj["_bytes_per_sample"] * local_samples)
             except Exception:
                 traffic = None
         out = {
@@ -195,6 +212,16 @@ def main():
                          "counters_per_sample": {k: round(v / st["samples"], 4) for k, v in st.items() if k not in ("samples", "max_stack")}},
             "setup_s": {"scene_and_bvh_build": round(t_build, 2), "upload": round(t_upload, 2)},
         }
+        if args.rehearse:
+            out["rehearsal"] = "all ranks on cuda:0, gloo gather through host copies: not a measurement"
+            # the assembled frame must equal what one rank renders alone (the image is a pure function of scene and seed)
+            ds.set_partition(0, 1)
+            ds.bind_accum(0, 0)
+            ds.clear()
+            ds.render(0, min(spp, 32), SEED)
+            single = torch.from_numpy(ds.read()).to(dev).reshape(-1)
+            ds.set_partition(rank, world)
+            out["rehearsal_frame_check"] = "skipped (spp > 32)" if spp > 32 else bool(torch.equal(single, image))
         if world == 1 and not args.no_cpu_baseline:
             import orc  # TEST INFRASTRUCTURE, used here only as the timed CPU baseline
             t0 = time.time()
