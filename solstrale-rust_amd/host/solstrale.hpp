@@ -247,6 +247,9 @@ struct PostProcessors {
   double kernel_size_fraction = 0, threshold = 0, max_intensity = 0;  // Bloom
 };
 struct NopPostProcessor { static PostProcessors create() { return {}; } };  // src/post/nop.rs:11-17
+// src/post/oidn.rs:85-128: without the crate's optional `oidn-postprocessor` feature (its default build) the OIDN
+// post-processor IS the Nop post-processor and asks for no albedo/normal buffers; that is the behaviour mirrored here.
+struct OidnPostProcessor { static PostProcessors create() { return {}; } };
 struct BloomPostProcessor {
   // src/post/bloom.rs:27-47: throws std::invalid_argument("kernel_size_fraction must be between 0 and 0.5");
   // a NaN threshold / max_intensity means None (defaults |(1,1,1)| and f64::MAX)

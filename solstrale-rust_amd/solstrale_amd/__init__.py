@@ -5,7 +5,7 @@ include/solstrale_hip.h) and `_build/libsolstrale_host.so` (C++ mirror of the re
 binds them with ctypes; it contains no rendering code and no CPU fallback.
 """
 from . import _abi  # noqa: F401
-from .host import (AlbedoShader, BloomPostProcessor, CameraConfig, HostError, NopPostProcessor, NormalShader,  # noqa: F401
+from .host import (AlbedoShader, BloomPostProcessor, CameraConfig, HostError, NopPostProcessor, NormalShader, OidnPostProcessor,  # noqa: F401
                    PathTracingShader, RenderConfig, RotationX, RotationY, RotationZ, Scale, Scene, SceneBuilder, SimpleShader,
                    Translation)
 from .device import DeviceError, DeviceScene, device_count, record_sizes, world_tree_check  # noqa: F401

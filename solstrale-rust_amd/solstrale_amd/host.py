@@ -55,6 +55,11 @@ def NopPostProcessor():
     return (0, (0., 0., 0.))
 
 
+def OidnPostProcessor():
+    """src/post/oidn.rs:85-128: the crate's default build (no `oidn-postprocessor` feature) makes this the Nop post-processor."""
+    return NopPostProcessor()
+
+
 def BloomPostProcessor(kernel_size_fraction, threshold=None, max_intensity=None):
     """src/post/bloom.rs:27-47 (None = the reference's default; the range check happens where the chain is installed)."""
     nan = float("nan")

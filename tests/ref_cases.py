@@ -6,22 +6,25 @@ without the `oidn-postprocessor` feature is the Nop post-processor, src/post/oid
 resize, RMS score > 0.95) is insensitive to sample noise, so the CPU suite uses fewer samples to stay within minutes;
 the GPU suite uses the reference's counts.
 """
-from solstrale_amd import (PathTracingShader, RenderConfig, RotationX, RotationY, RotationZ, SimpleShader, scenes)
+from solstrale_amd import (OidnPostProcessor, PathTracingShader, RenderConfig, RotationX, RotationY, RotationZ, SimpleShader, scenes)
 
 
-def _rc(w, h, spp, shader=None):
-    return RenderConfig(w, h, spp, shader or PathTracingShader(50))
+def _rc(w, h, spp, shader=None, post=None):
+    return RenderConfig(w, h, spp, shader or PathTracingShader(50), post_processors=post)
+
+
+OIDN = [OidnPostProcessor()]  # tests/integration_tests.rs:118,133,148,162,179: `post_processors: vec![OidnPostProcessor::new()]`
 
 
 CASES = [
     ("pathTracing", lambda s: scenes.create_test_scene(_rc(200, 100, s)), 200, 100, 25, 25),
     ("simple", lambda s: scenes.create_test_scene(_rc(200, 100, s, SimpleShader())), 200, 100, 25, 8),
     ("uv", lambda s: scenes.create_uv_scene(_rc(200, 200, s)), 200, 200, 5, 5),
-    ("normal_mapping_disabled", lambda s: scenes.create_normal_mapping_scene(_rc(300, 300, s), (30., 30., 30.), False), 300, 300, 50, 12),
-    ("normal_mapping_1", lambda s: scenes.create_normal_mapping_scene(_rc(300, 300, s), (30., 30., 30.), True), 300, 300, 50, 12),
-    ("normal_mapping_2", lambda s: scenes.create_normal_mapping_scene(_rc(300, 300, s), (-30., 30., 30.), True), 300, 300, 50, 12),
-    ("normal_mapping_sphere_1", lambda s: scenes.create_normal_mapping_sphere_scene(_rc(300, 300, s), (-30., 30., 30.)), 300, 300, 50, 12),
-    ("normal_mapping_sphere_2", lambda s: scenes.create_normal_mapping_sphere_scene(_rc(300, 300, s), (30., 30., 30.)), 300, 300, 50, 12),
+    ("normal_mapping_disabled", lambda s: scenes.create_normal_mapping_scene(_rc(300, 300, s, post=OIDN), (30., 30., 30.), False), 300, 300, 50, 12),
+    ("normal_mapping_1", lambda s: scenes.create_normal_mapping_scene(_rc(300, 300, s, post=OIDN), (30., 30., 30.), True), 300, 300, 50, 12),
+    ("normal_mapping_2", lambda s: scenes.create_normal_mapping_scene(_rc(300, 300, s, post=OIDN), (-30., 30., 30.), True), 300, 300, 50, 12),
+    ("normal_mapping_sphere_1", lambda s: scenes.create_normal_mapping_sphere_scene(_rc(300, 300, s, post=OIDN), (-30., 30., 30.)), 300, 300, 50, 12),
+    ("normal_mapping_sphere_2", lambda s: scenes.create_normal_mapping_sphere_scene(_rc(300, 300, s, post=OIDN), (30., 30., 30.)), 300, 300, 50, 12),
     ("light_attenuation_0.1", lambda s: scenes.create_light_attenuation_scene(_rc(300, 300, s), 0.1), 300, 300, 50, 12),
     ("light_attenuation_0.8", lambda s: scenes.create_light_attenuation_scene(_rc(300, 300, s), 0.8), 300, 300, 50, 12),
     ("light_attenuation_-1", lambda s: scenes.create_light_attenuation_scene(_rc(300, 300, s), None), 300, 300, 50, 12),
