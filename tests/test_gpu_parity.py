@@ -256,6 +256,17 @@ def test_random_scenes_parity(seed):
     assert res["pixels"] == 40 * 32
 
 
+def test_world_without_a_tree():
+    """`Scene.world` may be a single primitive (no Bvh at all) or a Bvh of one or two primitives: nothing to collapse."""
+    for n in (0, 1, 2):
+        b = SceneBuilder()
+        light = b.Sphere((0., 0., 0.), 1., b.DiffuseLight(2., 3., 4.))
+        extra = [b.Quad((-2., -1.5, -2.), (4., 0., 0.), (0., 0., 4.), b.Lambertian(b.SolidColor(.6, .6, .6)))] if n == 2 else []
+        world = light if n == 0 else b.Bvh([light] + extra)
+        sc = b.finish(world, CameraConfig(40., 0., (0., 1., 6.), (0., 0., 0.), (0, 1, 0)), (.1, .2, .3), RenderConfig(48, 40, 8))
+        assert_parity(sc, 8)
+
+
 def test_degenerate_world_parity():
     """Coincident primitives, dust of 1e-4 spheres and a 5e3 sphere around everything (tests/test_world_tree.py checks the tree's
     structure on the CPU): quantisation grids spanning 8 orders of magnitude must still return the oracle's hits."""
