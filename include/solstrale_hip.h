@@ -226,6 +226,15 @@ int sol_sync(SolScene* scene);
  * src/renderer/mod.rs:261). Pixels owned by other ranks are written as 0 when world > 1. */
 int sol_read(SolScene* scene, float* rgb_sum);
 
+/* Auxiliary buffers of the first hit (src/renderer/mod.rs:175-204; consumed by denoising post-processors): samples
+ * [first, first + n) of the albedo colour (AlbedoShader on the primary hit, background colour on a miss) and of the shading
+ * normal (NormalShader, zero on a miss) are ADDED to two accumulators laid out like the colour accumulator (same partition).
+ * Independent of sol_render; sol_clear_aux zeroes them, sol_read_aux blocks and writes W*H*3 floats each, row 0 = top
+ * (either pointer may be NULL). */
+int sol_render_aux(SolScene* scene, uint32_t first_sample, uint32_t n_samples, uint64_t seed);
+int sol_clear_aux(SolScene* scene);
+int sol_read_aux(SolScene* scene, float* albedo_sum, float* normal_sum);
+
 /* Rank-0 side of the multi-GPU gather: `gathered` is device memory holding world compact buffers back to
  * back (rank r at offset r * sol_accum_floats()), as produced by an RCCL gather; writes the row-major image
  * (W*H*3 floats, row 0 = top) to device memory `image`. */

@@ -461,6 +461,7 @@ struct SolScene {
   DSphere* spheres = nullptr; DMedium* mediums = nullptr; DMat* mats = nullptr; DTex* texs = nullptr;
   uint8_t* texels = nullptr; uint32_t* lights = nullptr;
   float* acc_own = nullptr; float* acc = nullptr; size_t acc_floats = 0;
+  float* aux[2] = {nullptr, nullptr}; size_t aux_floats = 0;  // albedo / normal accumulators (sol_render_aux), same layout as acc
   float* partial = nullptr; size_t partial_floats = 0;
   float* image = nullptr;  // W*H*3 scratch for sol_read / sol_resolve_image
   uint8_t* rgb8 = nullptr;
@@ -601,7 +602,7 @@ void sol_scene_destroy(SolScene* s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   void* ptrs[] = {s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
                   s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters, s->pool, s->queue, s->wf_ctr,
-                  s->bloom_a, s->bloom_b, s->bloom_w};
+                  s->bloom_a, s->bloom_b, s->bloom_w, s->aux[0], s->aux[1]};
   if (s->wf_ctr_host) hipHostFree(s->wf_ctr_host);
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -1105,6 +1106,65 @@ int sol_read(SolScene* s, float* rgb_sum) {
                                s->acc_floats, s->stream));
   HIP_TRY(hipMemcpyAsync(rgb_sum, s->image, (size_t)s->S.width * s->S.height * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return SOL_OK;
+}
+
+// Auxiliary albedo / normal buffers (src/renderer/mod.rs:175-204): at depth 0 the reference evaluates AlbedoShader and
+// NormalShader on the hit of the primary ray (background / zero on a miss) and accumulates them beside the pixel colour.
+// Those are exactly the single-hit shaders of this library evaluated on the same primary ray - same (seed, pixel, sample)
+// key, hence the same jitter and camera ray - so the two planes are two primary-ray-only renders into their own
+// accumulators; no path-tracing kernel variant is needed. (For Blend materials the reference's extra scatter call draws its
+// branch independently of the path's, as the separate render does.)
+int sol_render_aux(SolScene* s, uint32_t first, uint32_t n, uint64_t seed) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->aux_floats != s->acc_floats || !s->aux[0]) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int k = 0; k < 2; ++k) {
+      if (s->aux[k]) hipFree(s->aux[k]);
+      s->aux[k] = nullptr;
+      HIP_TRY(hipMalloc((void**)&s->aux[k], std::max<size_t>(s->acc_floats * sizeof(float), 64)));
+      HIP_TRY(hipMemsetAsync(s->aux[k], 0, std::max<size_t>(s->acc_floats * sizeof(float), 64), s->stream));
+    }
+    s->aux_floats = s->acc_floats;
+  }
+  float* const acc = s->acc;
+  const uint32_t shader = s->S.shader;
+  const uint32_t kinds[2] = {SOL_SHADER_ALBEDO, SOL_SHADER_NORMAL};
+  int rc = SOL_OK;
+  const float bg[3] = {s->S.bgx, s->S.bgy, s->S.bgz};
+  for (int k = 0; k < 2 && rc == SOL_OK; ++k) {
+    s->acc = s->aux[k];
+    s->S.shader = kinds[k];
+    if (k == 1) s->S.bgx = s->S.bgy = s->S.bgz = 0.0f;  // a miss: albedo = background colour, normal = ZERO_VECTOR (mod.rs:197-204)
+    rc = render_impl(s, first, n, seed, false);
+  }
+  s->acc = acc;
+  s->S.shader = shader;
+  s->S.bgx = bg[0]; s->S.bgy = bg[1]; s->S.bgz = bg[2];
+  return rc;
+}
+
+int sol_clear_aux(SolScene* s) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  for (int k = 0; k < 2; ++k)
+    if (s->aux[k] && s->aux_floats == s->acc_floats) HIP_TRY(hipMemsetAsync(s->aux[k], 0, s->aux_floats * sizeof(float), s->stream));
+  return SOL_OK;
+}
+
+int sol_read_aux(SolScene* s, float* albedo_sum, float* normal_sum) {
+  if (!s || (!albedo_sum && !normal_sum)) return fail(SOL_EINVAL, "null argument");
+  if (!s->aux[0] || s->aux_floats != s->acc_floats) return fail(SOL_EINVAL, "no auxiliary buffers: call sol_render_aux first");
+  HIP_TRY(hipSetDevice(s->device));
+  float* outs[2] = {albedo_sum, normal_sum};
+  for (int k = 0; k < 2; ++k) {
+    if (!outs[k]) continue;
+    HIP_TRY(sol_launch_unpermute(s->aux[k], s->image, s->S.width, s->S.height, s->blocks_x, (uint32_t)s->world, (uint32_t)s->rank,
+                                 s->acc_floats, s->stream));
+    HIP_TRY(hipMemcpyAsync(outs[k], s->image, (size_t)s->S.width * s->S.height * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
   return SOL_OK;
 }
 

@@ -154,6 +154,9 @@ def load_hip():
     _sig(lib, "sol_render_counted", C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint64])
     _sig(lib, "sol_sync", C.c_int, [P])
     _sig(lib, "sol_read", C.c_int, [P, C.POINTER(C.c_float)])
+    _sig(lib, "sol_render_aux", C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint64])
+    _sig(lib, "sol_clear_aux", C.c_int, [P])
+    _sig(lib, "sol_read_aux", C.c_int, [P, C.POINTER(C.c_float), C.POINTER(C.c_float)])
     _sig(lib, "sol_unpermute", C.c_int, [P, C.c_void_p, C.c_int, C.c_void_p])
     _sig(lib, "sol_tonemap_rgb8", C.c_int, [P, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint8)])
     _sig(lib, "sol_resolve_image", C.c_int, [P, C.POINTER(C.c_void_p)])
@@ -176,7 +179,7 @@ HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol
                "sol_accum_floats", "sol_accum_ptr", "sol_scene_bind_accum", "sol_scene_set_stream", "sol_clear",
                "sol_render", "sol_render_counted", "sol_sync", "sol_read", "sol_unpermute", "sol_tonemap_rgb8",
                "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms",
-               "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check"]
+               "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check", "sol_render_aux", "sol_clear_aux", "sol_read_aux"]
 
 
 def load_host():

@@ -109,6 +109,20 @@ class DeviceScene:
         self._chk(self.lib.sol_read(self.h, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def render_aux(self, first_sample, n_samples, seed):
+        """Adds the samples' first-hit albedo and normal to the auxiliary accumulators (renderer/mod.rs:175-204)."""
+        self._chk(self.lib.sol_render_aux(self.h, first_sample, n_samples, seed))
+
+    def clear_aux(self):
+        self._chk(self.lib.sol_clear_aux(self.h))
+
+    def read_aux(self):
+        """(albedo sums, normal sums), each (H, W, 3) float32, row 0 = top."""
+        a = np.empty((self.height, self.width, 3), dtype=np.float32)
+        n = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._chk(self.lib.sol_read_aux(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), n.ctypes.data_as(C.POINTER(C.c_float))))
+        return a, n
+
     def unpermute(self, gathered_ptr, world, image_ptr):
         self._chk(self.lib.sol_unpermute(self.h, C.c_void_p(gathered_ptr), world, C.c_void_p(image_ptr)))
 

@@ -392,3 +392,32 @@ def test_full_size_c2_properties():
     assert 0.12 < owned.mean() < 0.13 and (r3[owned] == whole[owned]).all() and not r3[~owned].any()
     ref, _ = orc.render(sc, 0, 256, pu.SEED, real=orc.ORC_F32, rect=(960, 540, 992, 572))
     assert pu.compare(whole, ref, 256, rect=(960, 540, 992, 572))["bad_pixels"] == 0
+
+
+def test_aux_albedo_and_normal_buffers():
+    """renderer/mod.rs:175-204: at depth 0 the albedo shader's and the normal shader's colours of the primary hit are accumulated
+    beside the pixel colour (background / zero on a miss). They equal the single-hit shaders' renders of the same samples."""
+    spp = 6
+    sc = scenes.create_test_scene(RenderConfig(120, 60, spp))  # background (.2, .3, .5), sky visible
+    with DeviceScene(sc) as ds:
+        ds.render(0, spp, pu.SEED)
+        colour = ds.read()
+        ds.render_aux(0, 2, pu.SEED)
+        ds.render_aux(2, spp - 2, pu.SEED)  # additive over sample ranges like the colour accumulator
+        albedo, normal = ds.read_aux()
+        assert (ds.read() == colour).all()  # the colour accumulator is untouched
+        ds.clear_aux()
+        ds.render_aux(0, spp, pu.SEED)
+        a2, n2 = ds.read_aux()
+    want_a, _ = orc.render(scenes.create_test_scene(RenderConfig(120, 60, spp, AlbedoShader())), 0, spp, pu.SEED, real=orc.ORC_F32)
+    sc_n = scenes.create_test_scene(RenderConfig(120, 60, spp, NormalShader()))
+    for k in range(3):
+        sc_n.desc.background[k] = 0.  # a miss adds ZERO_VECTOR to the normal buffer (mod.rs:203), not the background
+    want_n, _ = orc.render(sc_n, 0, spp, pu.SEED, real=orc.ORC_F32)
+    assert pu.compare(albedo, want_a, spp)["bad_pixels"] == 0
+    assert np.abs(normal - want_n).max() <= 1e-5 * spp  # components of a normal are <= 1 in magnitude
+    assert np.abs(a2 - albedo).max() <= 1e-5 * spp and np.abs(n2 - normal).max() <= 1e-5 * spp
+    # pixels whose every sample missed: albedo = spp * background, normal = 0
+    bg = np.array([.2, .3, .5], np.float32)
+    sky = np.all(want_n == 0., axis=2) & np.all(np.abs(want_a - spp * bg) < 1e-6, axis=2)
+    assert sky.sum() > 500 and (normal[sky] == 0.).all() and np.abs(albedo[sky] - spp * bg).max() < 1e-5
