@@ -456,6 +456,7 @@ struct SolScene {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevScene S{};
+  DevScene* dscene = nullptr; DevScene S_uploaded{}; bool dscene_valid = false;  // device copy of S (the v1 kernel reads it through a pointer)
   // owned device buffers
   DNode* nodes = nullptr; DWide* wides = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
   DSphere* spheres = nullptr; DMedium* mediums = nullptr; DMat* mats = nullptr; DTex* texs = nullptr;
@@ -602,7 +603,7 @@ void sol_scene_destroy(SolScene* s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   void* ptrs[] = {s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
                   s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters, s->pool, s->queue, s->wf_ctr,
-                  s->bloom_a, s->bloom_b, s->bloom_w, s->aux[0], s->aux[1]};
+                  s->bloom_a, s->bloom_b, s->bloom_w, s->aux[0], s->aux[1], s->dscene};
   if (s->wf_ctr_host) hipHostFree(s->wf_ctr_host);
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -1069,7 +1070,15 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
     }
     s->last_rounds = rounds;
   } else {
-    HIP_TRY(sol_launch_render(version, s->S, P, s->acc, s->partial, s->work, s->spill, s->pool, s->counters, grid, count,
+    if (!s->dscene) HIP_TRY(hipMalloc((void**)&s->dscene, sizeof(DevScene)));
+    if (!s->dscene_valid || std::memcmp(&s->S, &s->S_uploaded, sizeof(DevScene)) != 0) {
+      // rare (scene creation, tree probe, auxiliary renders): launches already queued may still read the old copy
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      HIP_TRY(hipMemcpy(s->dscene, &s->S, sizeof(DevScene), hipMemcpyHostToDevice));
+      std::memcpy(&s->S_uploaded, &s->S, sizeof(DevScene));
+      s->dscene_valid = true;
+    }
+    HIP_TRY(sol_launch_render(version, s->S, s->dscene, P, s->acc, s->partial, s->work, s->spill, s->pool, s->counters, grid, count,
                               s->has_medium, s->stream));
   }
   if (s->timing) { HIP_TRY(hipEventRecord(s->ev_stop, s->stream)); s->timed_launches++; }

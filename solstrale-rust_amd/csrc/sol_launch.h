@@ -5,7 +5,7 @@
 #include "sol_types.h"
 
 // version 1: one path per lane; version 2: wave-private wavefront over a pool of path slots (default)
-hipError_t sol_launch_render(int version, const DevScene& S, const RenderParams& P, float* acc, float* partial, uint32_t* work,
+hipError_t sol_launch_render(int version, const DevScene& S, const DevScene* dS, const RenderParams& P, float* acc, float* partial, uint32_t* work,
                              uint32_t* spill, void* pool, DevCounters* cnt, uint32_t grid, bool count, bool medium,
                              hipStream_t stream);
 int sol_render_blocks_per_cu(int version, bool count, bool medium);
