@@ -18,6 +18,7 @@
 
 #include "../../include/solstrale_hip.h"
 #include "sol_launch.h"
+#include "sol_tree.h"
 #include "sol_types.h"
 
 namespace {
@@ -39,406 +40,7 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(SOL_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_));   \
   } while (0)
 
-struct Box {
-  float v[6];
-};
-const float F_INF = std::numeric_limits<float>::infinity();
-Box empty_box() { return Box{{F_INF, -F_INF, F_INF, -F_INF, F_INF, -F_INF}}; }
-// fp32 box contract (DESIGN.md "fp32 arithmetic contract"): cast, then pad outward by g_box_pad = S * 2^-20 where S is
-// the largest finite |coordinate| of the world's box and the camera origin. PAD_DELTA (1e-4, src/geo/mod.rs:11) is sized
-// for f64; in fp32 a flat box seen from a distant origin collapses ((554.99994+800) == (555.00006+800) == 1355.0f) and
-// the slab test t_min < t_max fails. With the pad every fp32 slab test is conservative.
-thread_local float g_box_pad = 0.0f;
-Box cast_box(const SolAabb& b) {
-  Box r;
-  for (int i = 0; i < 6; i += 2) {
-    r.v[i] = (float)b.v[i] - g_box_pad;
-    r.v[i + 1] = (float)b.v[i + 1] + g_box_pad;
-  }
-  return r;
-}
-float box_pad_for(const SolSceneDesc& d) {
-  float S = 0.0f;
-  auto take = [&](double v) { float a = std::fabs((float)v); if (std::isfinite(a) && a > S) S = a; };
-  const uint32_t k = SOL_REF_KIND(d.root), i = SOL_REF_INDEX(d.root);
-  const SolAabb* b = nullptr;
-  if (k == SOL_REF_NODE && i < d.n_nodes) b = &d.nodes[i].bbox;
-  else if (k == SOL_REF_SPHERE && i < d.n_spheres) b = &d.spheres[i].bbox;
-  else if (k == SOL_REF_QUAD && i < d.n_quads) b = &d.quads[i].bbox;
-  else if (k == SOL_REF_TRIANGLE && i < d.n_triangles) b = &d.triangles[i].bbox;
-  else if (k == SOL_REF_MEDIUM && i < d.n_mediums) b = &d.mediums[i].bbox;
-  if (b) for (int j = 0; j < 6; ++j) take(b->v[j]);
-  for (int j = 0; j < 3; ++j) take(d.camera.origin[j]);
-  return S * (1.0f / 1048576.0f);
-}
-
-// Converts the reference-shaped tree (own box per node) into device nodes (child boxes in the parent).
-struct TreeBuilder {
-  const SolSceneDesc& d;
-  std::vector<DNode> nodes;
-  std::vector<int32_t> dev_index;  // desc node -> device node (-1 not yet / collapsed)
-  std::vector<uint8_t> on_path;
-  uint32_t max_depth = 0;
-  std::string error;
-
-  explicit TreeBuilder(const SolSceneDesc& desc) : d(desc), dev_index(desc.n_nodes, -1), on_path(desc.n_nodes, 0) {}
-
-  bool prim_box(uint32_t ref, Box& box) {
-    uint32_t k = SOL_REF_KIND(ref), i = SOL_REF_INDEX(ref);
-    switch (k) {
-      case SOL_REF_SPHERE: if (i >= d.n_spheres) return false; box = cast_box(d.spheres[i].bbox); return true;
-      case SOL_REF_QUAD: if (i >= d.n_quads) return false; box = cast_box(d.quads[i].bbox); return true;
-      case SOL_REF_TRIANGLE: if (i >= d.n_triangles) return false; box = cast_box(d.triangles[i].bbox); return true;
-      case SOL_REF_MEDIUM: if (i >= d.n_mediums) return false; box = cast_box(d.mediums[i].bbox); return true;
-    }
-    return false;
-  }
-
-  // Returns the device reference of `ref` and the box the parent must test for it.
-  bool resolve(uint32_t ref, uint32_t depth, uint32_t& out_ref, Box& out_box) {
-    uint32_t k = SOL_REF_KIND(ref), i = SOL_REF_INDEX(ref);
-    if (k == SOL_REF_NONE) { out_ref = SOL_MAKE_REF(SOL_REF_NONE, 0); out_box = empty_box(); return true; }
-    if (k != SOL_REF_NODE) {
-      if (!prim_box(ref, out_box)) { error = "primitive reference out of range"; return false; }
-      out_ref = ref;
-      return true;
-    }
-    if (i >= d.n_nodes) { error = "node reference out of range"; return false; }
-    if (on_path[i]) { error = "cycle in BVH"; return false; }
-    if (depth > 4000) { error = "BVH nesting deeper than 4000"; return false; }
-    const SolBvhNode& n = d.nodes[i];
-    const uint32_t lk = SOL_REF_KIND(n.left), rk = SOL_REF_KIND(n.right);
-    if (rk == SOL_REF_NONE && lk != SOL_REF_NONE && lk != SOL_REF_NODE) {
-      // `new_bvh` of a single primitive (bvh.rs:85-90): Bvh{Leaf(a), None, box(a)}. The parent tests the node's box and
-      // goes straight to the primitive.
-      Box pb;
-      if (!prim_box(n.left, pb)) { error = "primitive reference out of range"; return false; }
-      out_ref = n.left;
-      out_box = cast_box(n.bbox);
-      return true;
-    }
-    if (dev_index[i] >= 0) {  // shared sub-tree
-      out_ref = SOL_MAKE_REF(SOL_REF_NODE, (uint32_t)dev_index[i]);
-      out_box = cast_box(n.bbox);
-      return true;
-    }
-    const uint32_t di = (uint32_t)nodes.size();
-    if (di >= 0x0FFFFFFFu) { error = "too many nodes"; return false; }
-    dev_index[i] = (int32_t)di;
-    nodes.push_back(DNode{});
-    on_path[i] = 1;
-    if (depth + 1 > max_depth) max_depth = depth + 1;
-    uint32_t lr, rr;
-    Box lb, rb;
-    if (!resolve(n.left, depth + 1, lr, lb) || !resolve(n.right, depth + 1, rr, rb)) return false;
-    on_path[i] = 0;
-#ifdef SOL_NO_LEAF_BOX  // debug variant: no extra per-primitive boxes in two-leaf nodes (the reference tests none)
-    if (lk != SOL_REF_NONE && lk != SOL_REF_NODE) lb = Box{{-F_INF, F_INF, -F_INF, F_INF, -F_INF, F_INF}};
-    if (rk != SOL_REF_NONE && rk != SOL_REF_NODE) rb = Box{{-F_INF, F_INF, -F_INF, F_INF, -F_INF, F_INF}};
-#endif
-    DNode& dn = nodes[di];
-    dn.lxmin = lb.v[0]; dn.lxmax = lb.v[1]; dn.lymin = lb.v[2]; dn.lymax = lb.v[3]; dn.lzmin = lb.v[4]; dn.lzmax = lb.v[5];
-    dn.rxmin = rb.v[0]; dn.rxmax = rb.v[1]; dn.rymin = rb.v[2]; dn.rymax = rb.v[3]; dn.rzmin = rb.v[4]; dn.rzmax = rb.v[5];
-    dn.left = lr; dn.right = rr; dn.pad1 = 0;
-    // flags: bit0 / bit1 = the left / right box is a direct leaf's own box, which the reference never tests (sol_trace.h)
-    dn.pad0 = ((lk != SOL_REF_NONE && lk != SOL_REF_NODE) ? 1u : 0u) | ((rk != SOL_REF_NONE && rk != SOL_REF_NODE) ? 2u : 0u);
-    out_ref = SOL_MAKE_REF(SOL_REF_NODE, di);
-    out_box = cast_box(n.bbox);
-    return true;
-  }
-};
-
-// Collapses the binary device tree into 8-wide nodes with 8-bit quantised child boxes (DWide, sol_types.h). Pure layout:
-// every decoded child box CONTAINS the child's padded fp32 box (checked with the device's own decode arithmetic), so the
-// wide tree culls no ray that the binary tree would not; closest hits (t, tie rule on dfs_index) are identical.
-struct WideBuilder {
-  const std::vector<DNode>& bin;
-  std::vector<DWide> out;
-  uint32_t max_depth = 0;
-  // surface-area estimate of a random ray's work: summed box areas of the children that are wide nodes / primitives
-  // (a child is visited with probability ~ its area / the root's area)
-  bool slot_by_assignment = !(std::getenv("SOL_SLOTS") && std::strcmp(std::getenv("SOL_SLOTS"), "octant") == 0);
-  double inner_area = 0., leaf_area = 0.;
-  double cost() const { return 2.5 * inner_area + leaf_area; }  // a wide-node visit costs ~2.5 primitive tests (instructions)
-  struct Child { uint32_t ref; Box box; };
-
-  explicit WideBuilder(const std::vector<DNode>& b) : bin(b) {}
-
-  static Box lbox(const DNode& n) { return Box{{n.lxmin, n.lxmax, n.lymin, n.lymax, n.lzmin, n.lzmax}}; }
-  static Box rbox(const DNode& n) { return Box{{n.rxmin, n.rxmax, n.rymin, n.rymax, n.rzmin, n.rzmax}}; }
-  static float area(const Box& b) {
-    float dx = b.v[1] - b.v[0], dy = b.v[3] - b.v[2], dz = b.v[5] - b.v[4];
-    if (!(dx >= 0.f && dy >= 0.f && dz >= 0.f)) return 0.f;
-    return dx * dy + dy * dz + dz * dx;
-  }
-  static float decode(float origin, uint32_t q, float scale) { return origin + (float)q * scale; }  // == device decode
-
-  // Returns the reference to use for binary node `ni`: a wide node, or - when the node has a single child - that child.
-  uint32_t build(uint32_t ni, uint32_t depth) {
-    std::vector<Child> c;
-    auto add = [&](uint32_t ref, const Box& b) { if (SOL_REF_KIND(ref) != SOL_REF_NONE) c.push_back(Child{ref, b}); };
-    add(bin[ni].left, lbox(bin[ni]));
-    add(bin[ni].right, rbox(bin[ni]));
-    while (c.size() < 8) {  // open the inner child with the largest surface until eight children (or only leaves) remain
-      int best = -1;
-      float best_a = -1.f;
-      for (size_t i = 0; i < c.size(); ++i)
-        if (SOL_REF_KIND(c[i].ref) == SOL_REF_NODE) {
-          const DNode& n = bin[SOL_REF_INDEX(c[i].ref)];
-          int kids = (SOL_REF_KIND(n.left) != SOL_REF_NONE) + (SOL_REF_KIND(n.right) != SOL_REF_NONE);
-          if (c.size() - 1 + kids > 8) continue;
-          float a = area(c[i].box);
-          if (a > best_a) { best_a = a; best = (int)i; }
-        }
-      if (best < 0) break;
-      const DNode n = bin[SOL_REF_INDEX(c[best].ref)];
-      c.erase(c.begin() + best);
-      add(n.left, lbox(n));
-      add(n.right, rbox(n));
-    }
-    const uint32_t wi = (uint32_t)out.size();
-    out.push_back(DWide{});
-    if (depth + 1 > max_depth) max_depth = depth + 1;
-    for (auto& ch : c) (SOL_REF_KIND(ch.ref) == SOL_REF_NODE ? inner_area : leaf_area) += (double)area(ch.box);
-    // node box and quantisation grid
-    float lo[3] = {F_INF, F_INF, F_INF}, hi[3] = {-F_INF, -F_INF, -F_INF};
-    for (auto& ch : c)
-      for (int a = 0; a < 3; ++a) {
-        if (std::isfinite(ch.box.v[2 * a])) lo[a] = std::min(lo[a], ch.box.v[2 * a] - g_box_pad);
-        if (std::isfinite(ch.box.v[2 * a + 1])) hi[a] = std::max(hi[a], ch.box.v[2 * a + 1] + g_box_pad);
-      }
-    uint32_t eb[3];
-    float scale[3];
-    for (int a = 0; a < 3; ++a) {
-      if (!(hi[a] >= lo[a])) { lo[a] = 0.f; hi[a] = 0.f; }
-      int e = 1;
-      float ext = hi[a] - lo[a];
-      if (ext > 0.f && std::isfinite(ext)) {
-        int ex;
-        std::frexp(ext / 255.0f, &ex);  // ext/255 = m * 2^ex, m in [0.5,1)  ->  2^ex >= ext/255
-        e = std::min(254, std::max(1, ex + 127));
-      }
-      eb[a] = (uint32_t)e;
-      uint32_t bits = eb[a] << 23;
-      std::memcpy(&scale[a], &bits, 4);
-    }
-    // slots by octant of the child's centre (x << 2 | y << 1 | z), nearest free slot on conflict
-    float ctr[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
-    int slot_of[8];
-    bool used[8] = {false, false, false, false, false, false, false, false};
-    if (slot_by_assignment) {
-      // The device visits the hit children in the order slot ^ ray_octant, i.e. slot s is "far" along direction
-      // (+-1, +-1, +-1)_s. Give child i slot s so that the summed projections of the child centres on their slots'
-      // directions is largest (an 8x8 assignment problem, solved exactly: Kuhn-Munkres with potentials).
-      const int n = (int)c.size(), m = 8;
-      double cost[9][9];
-      for (int i = 1; i <= n; ++i) {
-        const Box& b = c[i - 1].box;
-        const double off[3] = {0.5 * ((double)b.v[0] + b.v[1]) - ctr[0], 0.5 * ((double)b.v[2] + b.v[3]) - ctr[1],
-                               0.5 * ((double)b.v[4] + b.v[5]) - ctr[2]};
-        for (int s = 0; s < m; ++s) {
-          double d = ((s & 4) ? off[0] : -off[0]) + ((s & 2) ? off[1] : -off[1]) + ((s & 1) ? off[2] : -off[2]);
-          cost[i][s + 1] = std::isfinite(d) ? -d : 0.;
-        }
-      }
-      double u[9] = {0}, v[9] = {0};
-      int p[9] = {0}, way[9] = {0};
-      for (int i = 1; i <= n; ++i) {
-        p[0] = i;
-        int j0 = 0;
-        double minv[9];
-        bool usedc[9];
-        for (int j = 0; j <= m; ++j) { minv[j] = std::numeric_limits<double>::infinity(); usedc[j] = false; }
-        do {
-          usedc[j0] = true;
-          const int i0 = p[j0];
-          double delta = std::numeric_limits<double>::infinity();
-          int j1 = 0;
-          for (int j = 1; j <= m; ++j)
-            if (!usedc[j]) {
-              const double cur = cost[i0][j] - u[i0] - v[j];
-              if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
-              if (minv[j] < delta) { delta = minv[j]; j1 = j; }
-            }
-          for (int j = 0; j <= m; ++j)
-            if (usedc[j]) { u[p[j]] += delta; v[j] -= delta; } else minv[j] -= delta;
-          j0 = j1;
-        } while (p[j0] != 0);
-        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
-      }
-      for (int j = 1; j <= m; ++j)
-        if (p[j] > 0) { slot_of[p[j] - 1] = j - 1; used[j - 1] = true; }
-    } else {
-      std::vector<size_t> order(c.size());
-      for (size_t i = 0; i < c.size(); ++i) order[i] = i;
-      std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return area(c[a].box) > area(c[b].box); });
-      for (size_t oi : order) {
-        const Box& b = c[oi].box;
-        int pref = ((0.5f * (b.v[0] + b.v[1]) > ctr[0]) ? 4 : 0) | ((0.5f * (b.v[2] + b.v[3]) > ctr[1]) ? 2 : 0) |
-                   ((0.5f * (b.v[4] + b.v[5]) > ctr[2]) ? 1 : 0);
-        int best = -1, best_d = 99;
-        for (int s = 0; s < 8; ++s)
-          if (!used[s]) {
-            int d = __builtin_popcount((unsigned)(s ^ pref));
-            if (d < best_d) { best_d = d; best = s; }
-          }
-        used[best] = true;
-        slot_of[oi] = best;
-      }
-    }
-    uint32_t q[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t refs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // empty slots: inverted box (lo = 255, hi = 0) and a NONE reference
-    for (int s = 0; s < 8; ++s)
-      if (!used[s])
-        for (int a = 0; a < 3; ++a) q[2 * a + (s >> 2)] |= 255u << (8 * (s & 3));
-    for (size_t i = 0; i < c.size(); ++i) {
-      const int s = slot_of[i];
-      for (int a = 0; a < 3; ++a) {
-        // one more box pad on top of the padded fp32 box: the device evaluates these planes in t-space (A + q * B), whose
-        // rounding error is up to ~0.7 pad; with the extra pad the margin is 3x
-        float cl = c[i].box.v[2 * a] - g_box_pad, chh = c[i].box.v[2 * a + 1] + g_box_pad;
-        if (!std::isfinite(cl)) cl = lo[a];
-        if (!std::isfinite(chh)) chh = hi[a];
-        long ql = (long)std::floor((cl - lo[a]) / scale[a]);
-        long qh = (long)std::ceil((chh - lo[a]) / scale[a]);
-        ql = std::min(255L, std::max(0L, ql));
-        qh = std::min(255L, std::max(0L, qh));
-        while (ql > 0 && decode(lo[a], (uint32_t)ql, scale[a]) > cl) --ql;      // conservative under the device's rounding
-        while (qh < 255 && decode(lo[a], (uint32_t)qh, scale[a]) < chh) ++qh;
-        if (decode(lo[a], (uint32_t)ql, scale[a]) > cl || decode(lo[a], (uint32_t)qh, scale[a]) < chh) {
-          // cannot happen: 255 * scale >= extent; be safe and open the box fully on this axis
-          ql = 0; qh = 255;
-        }
-        q[2 * a + (s >> 2)] |= (uint32_t)ql << (8 * (s & 3));
-        q[6 + 2 * a + (s >> 2)] |= (uint32_t)qh << (8 * (s & 3));
-      }
-      uint32_t r = c[i].ref;
-      if (SOL_REF_KIND(r) == SOL_REF_NODE) r = build(SOL_REF_INDEX(r), depth + 1);
-      refs[s] = r;
-    }
-    DWide& w = out[wi];
-    w.ox = lo[0]; w.oy = lo[1]; w.oz = lo[2];
-    w.meta = eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)c.size() << 24);
-    for (int k = 0; k < 12; ++k) w.q[k] = q[k];
-    for (int k = 0; k < 8; ++k) w.ref[k] = refs[k];
-    return SOL_MAKE_REF(SOL_REF_WIDE, wi);
-  }
-};
-
-// Rebuilds the WORLD's binary tree over the same primitives with a binned surface-area heuristic. The closest hit of a
-// search does not depend on the tree (every box bounds its primitives, ties are decided by the primitives' dfs_index in
-// the REFERENCE tree, which stays on the records), so the device is free to walk a better tree than the reference's
-// centroid-median one (bvh.rs:118-162); only the world search (t >= 0.001) uses it, constant-medium boundaries keep the
-// reference-shaped tree and its negative-t rules. Output has TreeBuilder's format (child boxes in the parent).
-struct SahBuilder {
-  struct Prim { uint32_t ref; Box box; float c[3]; };
-  std::vector<Prim> prims;
-  std::vector<DNode> nodes;
-  static constexpr int MAX_BINS = 64;
-  int BINS = 16;
-
-  // Leaves of the reference-shaped device tree under `root` (a shared sub-tree contributes its leaves once per use).
-  bool collect(const std::vector<DNode>& bin, uint32_t root) {
-    std::vector<std::pair<uint32_t, Box>> stk;
-    stk.push_back({root, empty_box()});
-    while (!stk.empty()) {
-      auto [ref, box] = stk.back();
-      stk.pop_back();
-      const uint32_t k = SOL_REF_KIND(ref);
-      if (k == SOL_REF_NONE) continue;
-      if (k == SOL_REF_NODE) {
-        const DNode& n = bin[SOL_REF_INDEX(ref)];
-        stk.push_back({n.right, WideBuilder::rbox(n)});
-        stk.push_back({n.left, WideBuilder::lbox(n)});
-        continue;
-      }
-      Prim p{ref, box, {0.f, 0.f, 0.f}};
-      for (int a = 0; a < 3; ++a) {
-        if (!std::isfinite(box.v[2 * a]) || !std::isfinite(box.v[2 * a + 1]) || box.v[2 * a] > box.v[2 * a + 1]) return false;
-        p.c[a] = 0.5f * (box.v[2 * a] + box.v[2 * a + 1]);
-      }
-      if (prims.size() >= (1u << 26)) return false;
-      prims.push_back(p);
-    }
-    return prims.size() >= 2;
-  }
-  static void grow(Box& b, const Box& o) {
-    for (int a = 0; a < 3; ++a) { b.v[2 * a] = std::min(b.v[2 * a], o.v[2 * a]); b.v[2 * a + 1] = std::max(b.v[2 * a + 1], o.v[2 * a + 1]); }
-  }
-  static double area(const Box& b) {
-    double dx = (double)b.v[1] - b.v[0], dy = (double)b.v[3] - b.v[2], dz = (double)b.v[5] - b.v[4];
-    if (!(dx >= 0. && dy >= 0. && dz >= 0.)) return 0.;
-    return dx * dy + dy * dz + dz * dx;
-  }
-  // Builds [lo, hi) and returns its reference and box.
-  uint32_t build(size_t lo, size_t hi, uint32_t depth, Box& out_box) {
-    if (hi - lo == 1) { out_box = prims[lo].box; return prims[lo].ref; }
-    float cmin[3] = {F_INF, F_INF, F_INF}, cmax[3] = {-F_INF, -F_INF, -F_INF};
-    for (size_t i = lo; i < hi; ++i)
-      for (int a = 0; a < 3; ++a) { cmin[a] = std::min(cmin[a], prims[i].c[a]); cmax[a] = std::max(cmax[a], prims[i].c[a]); }
-    int best_axis = -1, best_bin = -1;
-    double best_cost = std::numeric_limits<double>::infinity();
-    float best_k = 0.f;
-    if (depth < 48)
-      for (int a = 0; a < 3; ++a) {
-        const float ext = cmax[a] - cmin[a];
-        if (!(ext > 0.f)) continue;
-        const float k = (float)BINS / ext;
-        Box bb[MAX_BINS];
-        uint32_t bn[MAX_BINS];
-        for (int b = 0; b < BINS; ++b) { bb[b] = empty_box(); bn[b] = 0; }
-        for (size_t i = lo; i < hi; ++i) {
-          int b = std::min(BINS - 1, std::max(0, (int)((prims[i].c[a] - cmin[a]) * k)));
-          grow(bb[b], prims[i].box);
-          bn[b]++;
-        }
-        double ra[MAX_BINS];
-        uint32_t rn[MAX_BINS];
-        Box acc = empty_box();
-        uint32_t n = 0;
-        for (int b = BINS - 1; b > 0; --b) { grow(acc, bb[b]); n += bn[b]; ra[b] = area(acc); rn[b] = n; }
-        acc = empty_box();
-        n = 0;
-        for (int b = 0; b < BINS - 1; ++b) {  // split after bin b
-          grow(acc, bb[b]);
-          n += bn[b];
-          if (n == 0 || rn[b + 1] == 0) continue;
-          const double cost = area(acc) * n + ra[b + 1] * rn[b + 1];
-          if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; best_k = k; }
-        }
-      }
-    size_t mid;
-    if (best_axis >= 0) {
-      const int a = best_axis;
-      const float c0 = cmin[a];
-      auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [&](const Prim& p) {
-        return std::min(BINS - 1, std::max(0, (int)((p.c[a] - c0) * best_k))) <= best_bin;
-      });
-      mid = (size_t)(it - prims.begin());
-    } else {
-      mid = lo;
-    }
-    if (mid == lo || mid == hi) {  // coincident centroids (or the depth guard): median along the widest axis
-      int a = 0;
-      for (int k = 1; k < 3; ++k) if (cmax[k] - cmin[k] > cmax[a] - cmin[a]) a = k;
-      mid = lo + (hi - lo) / 2;
-      std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi, [a](const Prim& x, const Prim& y) { return x.c[a] < y.c[a]; });
-    }
-    const uint32_t ni = (uint32_t)nodes.size();
-    nodes.push_back(DNode{});
-    Box lb, rb;
-    const uint32_t lr = build(lo, mid, depth + 1, lb);
-    const uint32_t rr = build(mid, hi, depth + 1, rb);
-    DNode& dn = nodes[ni];
-    dn.lxmin = lb.v[0]; dn.lxmax = lb.v[1]; dn.lymin = lb.v[2]; dn.lymax = lb.v[3]; dn.lzmin = lb.v[4]; dn.lzmax = lb.v[5];
-    dn.rxmin = rb.v[0]; dn.rxmax = rb.v[1]; dn.rymin = rb.v[2]; dn.rymax = rb.v[3]; dn.rzmin = rb.v[4]; dn.rzmax = rb.v[5];
-    dn.left = lr; dn.right = rr; dn.pad0 = dn.pad1 = 0;
-    out_box = lb;
-    grow(out_box, rb);
-    return SOL_MAKE_REF(SOL_REF_NODE, ni);
-  }
-};
+// Box, TreeBuilder, WideBuilder, SahBuilder: sol_tree.h (included above)
 
 template <typename T>
 int upload(const std::vector<T>& host, T** dev) {
