@@ -380,7 +380,12 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
       c.depth = depth_of(*c.wb);
       cands.push_back(std::move(c));
     }
-    for (int bins : {8, 16, 64}) {
+    std::vector<int> bin_list = {8, 16, 64};
+    if (const char* bl = std::getenv("SOL_SAH_LIST")) {  // experiment: other candidate sets, e.g. SOL_SAH_LIST=4,12,32
+      bin_list.clear();
+      for (const char* p = bl; *p;) { bin_list.push_back(std::max(2, std::min(64, std::atoi(p)))); while (*p && *p != ',') ++p; if (*p) ++p; }
+    }
+    for (int bins : bin_list) {
       const std::string name = "sah" + std::to_string(bins);
       if (want == "ref" || (!want.empty() && want != name)) continue;
       TreeCand c;
