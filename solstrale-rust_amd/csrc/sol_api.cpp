@@ -124,8 +124,8 @@ int sol_device_count(void) {
 int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) {
   if (!d || !out) return fail(SOL_EINVAL, "null argument");
   std::memset(out, 0, sizeof *out);
-  g_box_pad = box_pad_for(*d);
-  TreeBuilder tb(*d);
+  const float box_pad = box_pad_for(*d);
+  TreeBuilder tb(*d, box_pad);
   uint32_t root_ref;
   Box root_box;
   if (!tb.resolve(d->root, 0, root_ref, root_box)) return fail(SOL_EINVAL, "world: %s", tb.error.c_str());
@@ -138,7 +138,7 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
   out->n_primitives = (uint32_t)sah.prims.size();
   uint32_t bin_root = root_ref;
   if (use_sah) { Box b; sah.BINS = use_sah > 1 ? std::min((int)SahBuilder::MAX_BINS, use_sah) : 16; bin_root = sah.build(0, sah.prims.size(), 0, b); }
-  WideBuilder wb(use_sah ? sah.nodes : tb.nodes);
+  WideBuilder wb(use_sah ? sah.nodes : tb.nodes, box_pad);
   const uint32_t wroot = wb.build(SOL_REF_INDEX(bin_root), 0);
   out->n_wide = (uint32_t)wb.out.size();
   out->depth = wb.max_depth;
@@ -319,8 +319,8 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   }
 
   // ---- tree ----
-  g_box_pad = box_pad_for(*d);
-  TreeBuilder tb(*d);
+  const float box_pad = box_pad_for(*d);
+  TreeBuilder tb(*d, box_pad);
   uint32_t root_ref;
   Box root_box;
   if (!tb.resolve(d->root, 0, root_ref, root_box)) return fail(SOL_EINVAL, "world: %s", tb.error.c_str());
@@ -375,7 +375,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
     {
       TreeCand c;
       c.name = "ref";
-      c.wb.reset(new WideBuilder(tb.nodes));
+      c.wb.reset(new WideBuilder(tb.nodes, box_pad));
       c.wroot = c.wb->build(SOL_REF_INDEX(root_ref), 0);
       c.depth = depth_of(*c.wb);
       cands.push_back(std::move(c));
@@ -395,7 +395,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
       if (!c.sah->collect(tb.nodes, root_ref)) break;  // non-finite boxes or a single primitive: reference topology only
       Box bx;
       const uint32_t r = c.sah->build(0, c.sah->prims.size(), 0, bx);
-      c.wb.reset(new WideBuilder(c.sah->nodes));
+      c.wb.reset(new WideBuilder(c.sah->nodes, box_pad));
       c.wroot = c.wb->build(SOL_REF_INDEX(r), 0);
       c.depth = depth_of(*c.wb);
       cands.push_back(std::move(c));
@@ -464,7 +464,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   S.rxmin = root_box.v[0]; S.rxmax = root_box.v[1]; S.rymin = root_box.v[2]; S.rymax = root_box.v[3];
   S.rzmin = root_box.v[4]; S.rzmax = root_box.v[5];
   S.width = d->width; S.height = d->height; S.shader = d->shader_kind; S.max_depth = d->max_depth;
-  S.sphere_slack = g_box_pad * 0.5f;
+  S.sphere_slack = box_pad * 0.5f;
   S.bgx = (float)d->background[0]; S.bgy = (float)d->background[1]; S.bgz = (float)d->background[2];
   const SolCamera& c = d->camera;
   S.cam = DCamera{(float)c.origin[0], (float)c.origin[1], (float)c.origin[2],

@@ -27,16 +27,15 @@ struct Box {
 };
 const float F_INF = std::numeric_limits<float>::infinity();
 Box empty_box() { return Box{{F_INF, -F_INF, F_INF, -F_INF, F_INF, -F_INF}}; }
-// fp32 box contract (DESIGN.md "fp32 arithmetic contract"): cast, then pad outward by g_box_pad = S * 2^-20 where S is
+// fp32 box contract (DESIGN.md "fp32 arithmetic contract"): cast, then pad outward by pad = S * 2^-20 (box_pad_for) where S is
 // the largest finite |coordinate| of the world's box and the camera origin. PAD_DELTA (1e-4, src/geo/mod.rs:11) is sized
 // for f64; in fp32 a flat box seen from a distant origin collapses ((554.99994+800) == (555.00006+800) == 1355.0f) and
 // the slab test t_min < t_max fails. With the pad every fp32 slab test is conservative.
-thread_local float g_box_pad = 0.0f;
-Box cast_box(const SolAabb& b) {
+Box cast_box(const SolAabb& b, float pad) {
   Box r;
   for (int i = 0; i < 6; i += 2) {
-    r.v[i] = (float)b.v[i] - g_box_pad;
-    r.v[i + 1] = (float)b.v[i + 1] + g_box_pad;
+    r.v[i] = (float)b.v[i] - pad;
+    r.v[i + 1] = (float)b.v[i + 1] + pad;
   }
   return r;
 }
@@ -64,15 +63,16 @@ struct TreeBuilder {
   uint32_t max_depth = 0;
   std::string error;
 
-  explicit TreeBuilder(const SolSceneDesc& desc) : d(desc), dev_index(desc.n_nodes, -1), on_path(desc.n_nodes, 0) {}
+  const float pad;  // the fp32 box pad of this scene (box_pad_for)
+  TreeBuilder(const SolSceneDesc& desc, float box_pad) : d(desc), dev_index(desc.n_nodes, -1), on_path(desc.n_nodes, 0), pad(box_pad) {}
 
   bool prim_box(uint32_t ref, Box& box) {
     uint32_t k = SOL_REF_KIND(ref), i = SOL_REF_INDEX(ref);
     switch (k) {
-      case SOL_REF_SPHERE: if (i >= d.n_spheres) return false; box = cast_box(d.spheres[i].bbox); return true;
-      case SOL_REF_QUAD: if (i >= d.n_quads) return false; box = cast_box(d.quads[i].bbox); return true;
-      case SOL_REF_TRIANGLE: if (i >= d.n_triangles) return false; box = cast_box(d.triangles[i].bbox); return true;
-      case SOL_REF_MEDIUM: if (i >= d.n_mediums) return false; box = cast_box(d.mediums[i].bbox); return true;
+      case SOL_REF_SPHERE: if (i >= d.n_spheres) return false; box = cast_box(d.spheres[i].bbox, pad); return true;
+      case SOL_REF_QUAD: if (i >= d.n_quads) return false; box = cast_box(d.quads[i].bbox, pad); return true;
+      case SOL_REF_TRIANGLE: if (i >= d.n_triangles) return false; box = cast_box(d.triangles[i].bbox, pad); return true;
+      case SOL_REF_MEDIUM: if (i >= d.n_mediums) return false; box = cast_box(d.mediums[i].bbox, pad); return true;
     }
     return false;
   }
@@ -97,12 +97,12 @@ struct TreeBuilder {
       Box pb;
       if (!prim_box(n.left, pb)) { error = "primitive reference out of range"; return false; }
       out_ref = n.left;
-      out_box = cast_box(n.bbox);
+      out_box = cast_box(n.bbox, pad);
       return true;
     }
     if (dev_index[i] >= 0) {  // shared sub-tree
       out_ref = SOL_MAKE_REF(SOL_REF_NODE, (uint32_t)dev_index[i]);
-      out_box = cast_box(n.bbox);
+      out_box = cast_box(n.bbox, pad);
       return true;
     }
     const uint32_t di = (uint32_t)nodes.size();
@@ -126,7 +126,7 @@ struct TreeBuilder {
     // flags: bit0 / bit1 = the left / right box is a direct leaf's own box, which the reference never tests (sol_trace.h)
     dn.pad0 = ((lk != SOL_REF_NONE && lk != SOL_REF_NODE) ? 1u : 0u) | ((rk != SOL_REF_NONE && rk != SOL_REF_NODE) ? 2u : 0u);
     out_ref = SOL_MAKE_REF(SOL_REF_NODE, di);
-    out_box = cast_box(n.bbox);
+    out_box = cast_box(n.bbox, pad);
     return true;
   }
 };
@@ -145,7 +145,8 @@ struct WideBuilder {
   double cost() const { return 2.5 * inner_area + leaf_area; }  // a wide-node visit costs ~2.5 primitive tests (instructions)
   struct Child { uint32_t ref; Box box; };
 
-  explicit WideBuilder(const std::vector<DNode>& b) : bin(b) {}
+  const float pad;  // the fp32 box pad of this scene
+  WideBuilder(const std::vector<DNode>& b, float box_pad) : bin(b), pad(box_pad) {}
 
   static Box lbox(const DNode& n) { return Box{{n.lxmin, n.lxmax, n.lymin, n.lymax, n.lzmin, n.lzmax}}; }
   static Box rbox(const DNode& n) { return Box{{n.rxmin, n.rxmax, n.rymin, n.rymax, n.rzmin, n.rzmax}}; }
@@ -187,8 +188,8 @@ struct WideBuilder {
     float lo[3] = {F_INF, F_INF, F_INF}, hi[3] = {-F_INF, -F_INF, -F_INF};
     for (auto& ch : c)
       for (int a = 0; a < 3; ++a) {
-        if (std::isfinite(ch.box.v[2 * a])) lo[a] = std::min(lo[a], ch.box.v[2 * a] - g_box_pad);
-        if (std::isfinite(ch.box.v[2 * a + 1])) hi[a] = std::max(hi[a], ch.box.v[2 * a + 1] + g_box_pad);
+        if (std::isfinite(ch.box.v[2 * a])) lo[a] = std::min(lo[a], ch.box.v[2 * a] - pad);
+        if (std::isfinite(ch.box.v[2 * a + 1])) hi[a] = std::max(hi[a], ch.box.v[2 * a + 1] + pad);
       }
     uint32_t eb[3];
     float scale[3];
@@ -280,7 +281,7 @@ struct WideBuilder {
       for (int a = 0; a < 3; ++a) {
         // one more box pad on top of the padded fp32 box: the device evaluates these planes in t-space (A + q * B), whose
         // rounding error is up to ~0.7 pad; with the extra pad the margin is 3x
-        float cl = c[i].box.v[2 * a] - g_box_pad, chh = c[i].box.v[2 * a + 1] + g_box_pad;
+        float cl = c[i].box.v[2 * a] - pad, chh = c[i].box.v[2 * a + 1] + pad;
         if (!std::isfinite(cl)) cl = lo[a];
         if (!std::isfinite(chh)) chh = hi[a];
         long ql = (long)std::floor((cl - lo[a]) / scale[a]);
