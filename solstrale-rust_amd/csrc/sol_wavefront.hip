@@ -1,19 +1,20 @@
-// sol_wavefront.hip -- v3: the two-kernel WAVEFRONT used for large jobs (bit-identical to the single-launch kernels of
-// sol_render.hip: same device functions, same per-slot logic).
+// sol_wavefront.hip -- v3 (SOL_KERNEL=v3, A/B only): a two-kernel WAVEFRONT, bit-identical to the kernels of sol_render.hip
+// (same device functions, same per-slot logic). Kept as the measured alternative to the product kernel: it reaches a higher
+// lane occupancy in the search but loses more to per-round launches, per-round tails and 112 B of state traffic per vertex
+// (C3 at 128 spp: 830 against 1440 Msamples/s for sol_render_kernel).
 //
 // One global pool of path slots in HBM (112 B of state per slot, records as in sol_render.hip). Per round the host launches
 //   sol_wf_shade_kernel : one thread per slot. Shades the finished search of the slot's path (scatter, light/BSDF mixture
 //                         pdf, throughput update or termination), starts the next sample of its work item or takes a new
 //                         (pixel, 16-sample chunk) item from the wave's item reservoir (refilled 64 items per global atomic).
-//   sol_wf_trace_kernel : persistent waves. A wave takes a 1024-slot stretch of the pool with one atomic, reads the slots'
-//                         flags 64 at a time and COMPACTS the live ones onto its idle lanes with ballot + popcount + n-th-set-
-//                         bit selection - no ray queue exists in memory. Lanes search the BVH (ordered traversal, 16-entry
-//                         LDS stack + global spill); whenever enough lanes have finished they are refilled the same way, so
-//                         the traversal loop runs with nearly all lanes busy. Only (origin, direction, best hit) live in
-//                         registers: 64 VGPRs -> 8 waves/SIMD, which is what hides the node-fetch latency.
-// Global atomics per round: (slots / 1024) in the trace kernel, about (items taken / 64) in the shade kernel - the first
-// version of this design issued one atomic per 16 rays on one address and ran at the chip's single-address atomic rate
-// (about 88 M/s) instead of the traversal rate.
+//   sol_wf_trace_kernel : persistent waves. Wave w owns the 64-slot groups w, w + W, w + 2W, .. of the pool (static round
+//                         robin, no atomics); it reads a group's flags and COMPACTS the live slots onto its idle lanes with
+//                         ballot + popcount + n-th-set-bit selection - no ray queue exists in memory. Lanes search the BVH
+//                         (trav_step, LDS stack + global spill); whenever enough lanes have finished they are refilled the
+//                         same way. Only (origin, direction, best hit) live in registers, so the kernel is compiled for 5
+//                         waves per SIMD (SOL_WF_MIN_WAVES) against the product kernel's 4.
+// The first version of this design issued one global atomic per 16 rays on one address and ran at the chip's single-address
+// atomic rate (about 88 M/s) instead of the traversal rate - the lesson behind the product kernel's item reservoir.
 #include <hip/hip_runtime.h>
 
 #include "sol_launch.h"
