@@ -64,7 +64,9 @@ struct SolScene {
   DSphere* spheres = nullptr; DMedium* mediums = nullptr; DMat* mats = nullptr; DTex* texs = nullptr;
   uint8_t* texels = nullptr; uint32_t* lights = nullptr;
   float* acc_own = nullptr; float* acc = nullptr; size_t acc_floats = 0;
-  float* aux[2] = {nullptr, nullptr}; size_t aux_floats = 0;  // albedo / normal accumulators (sol_render_aux), same layout as acc
+  float* aux[2] = {nullptr, nullptr}; size_t aux_floats = 0;
+  std::vector<uint32_t> block_cost;  // per 8x8 block (global index): rays of its longest item in the cost probe; empty: no ordering
+  uint32_t* order_dev = nullptr; size_t order_cap = 0;  // DevScene::block_order of the current partition  // albedo / normal accumulators (sol_render_aux), same layout as acc
   float* partial = nullptr; size_t partial_floats = 0;
   float* image = nullptr;  // W*H*3 scratch for sol_read / sol_resolve_image
   uint8_t* rgb8 = nullptr;
@@ -91,6 +93,40 @@ struct SolScene {
   uint32_t timed_launches = 0, last_grid = 0;
 };
 
+// DevScene::block_order for the current partition from the probe's per-block costs: the blocks more than three times as
+// costly as the average come first, costliest first; everything else keeps its order. No heavy blocks: identity (null).
+static int rebuild_order(SolScene* s) {
+  s->S.block_order = nullptr;
+  s->S.n_first = 0;
+  const uint32_t n = s->n_local_blocks;
+  if (s->block_cost.empty() || n < 2) return SOL_OK;
+  std::vector<uint32_t> cost(n);
+  double sum = 0.;
+  for (uint32_t lb = 0; lb < n; ++lb) {
+    const size_t b = (size_t)lb * s->world + s->rank;
+    cost[lb] = b < s->block_cost.size() ? s->block_cost[b] : 0u;
+    sum += cost[lb];
+  }
+  const double limit = 3.0 * sum / n;
+  std::vector<uint32_t> heavy, rest;
+  for (uint32_t lb = 0; lb < n; ++lb) (cost[lb] > limit ? heavy : rest).push_back(lb);
+  if (heavy.empty() || rest.empty()) return SOL_OK;
+  std::stable_sort(heavy.begin(), heavy.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+  heavy.insert(heavy.end(), rest.begin(), rest.end());
+  if (n > s->order_cap) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->order_dev) hipFree(s->order_dev);
+    s->order_dev = nullptr; s->order_cap = 0;
+    HIP_TRY(hipMalloc((void**)&s->order_dev, (size_t)n * sizeof(uint32_t)));
+    s->order_cap = n;
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));  // a launch in flight may still read the old table
+  HIP_TRY(hipMemcpy(s->order_dev, heavy.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  s->S.block_order = s->order_dev;
+  s->S.n_first = (uint32_t)(heavy.size() - rest.size());
+  return SOL_OK;
+}
+
 static int set_partition(SolScene* s, int rank, int world) {
   if (world < 1 || rank < 0 || rank >= world) return fail(SOL_EINVAL, "bad partition %d/%d", rank, world);
   s->rank = rank; s->world = world;
@@ -106,10 +142,11 @@ static int set_partition(SolScene* s, int rank, int world) {
     s->acc = s->acc_own;
     s->acc_floats = floats;
   }
-  return SOL_OK;
+  return rebuild_order(s);
 }
 
 static int render_probe(SolScene* s);
+static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool count);
 
 extern "C" {
 
@@ -205,7 +242,7 @@ void sol_scene_destroy(SolScene* s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   void* ptrs[] = {s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
                   s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters, s->pool, s->queue, s->wf_ctr,
-                  s->bloom_a, s->bloom_b, s->bloom_w, s->aux[0], s->aux[1], s->dscene};
+                  s->bloom_a, s->bloom_b, s->bloom_w, s->aux[0], s->aux[1], s->dscene, s->order_dev};
   if (s->wf_ctr_host) hipHostFree(s->wf_ctr_host);
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -517,6 +554,26 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
     s->stats = SolStats{};
     if (rc || (rc = set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  // Cost probe: per 8x8 block, the ray count of the longest 4-sample item in a counted render of the whole frame, for the
+  // heavy-first work order
+  // (rebuild_order; sol_path.h decode_item_ordered). SOL_ORDER=0 switches it off.
+  if (!(std::getenv("SOL_ORDER") && std::atoi(std::getenv("SOL_ORDER")) == 0) && s->blocks_x * s->blocks_y >= 64u) {
+    const uint32_t nb = s->blocks_x * s->blocks_y;
+    uint32_t* cost_dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&cost_dev, (size_t)nb * sizeof(uint32_t)));
+    hipError_t e = hipMemset(cost_dev, 0, (size_t)nb * sizeof(uint32_t));
+    S.block_cost = cost_dev;
+    rc = e == hipSuccess ? render_impl(s, 0, 4, 0xC057ull, true) : SOL_EDEVICE;
+    S.block_cost = nullptr;
+    s->block_cost.assign(nb, 0u);
+    if (rc == SOL_OK && hipMemcpy(s->block_cost.data(), cost_dev, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = SOL_EDEVICE;
+    hipFree(cost_dev);
+    if (rc != SOL_OK) return rc == SOL_EDEVICE ? fail(SOL_EDEVICE, "cost probe failed") : rc;
+    s->stats = SolStats{};
+    if ((rc = sol_clear(s)) || (rc = rebuild_order(s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (std::getenv("SOL_VERBOSE")) std::fprintf(stderr, "[solstrale] work order: %u of %u blocks heavy (first)\n", S.n_first, s->n_local_blocks);
   }
   cleanup.keep = true;
   *out = s;

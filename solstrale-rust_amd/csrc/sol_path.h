@@ -137,6 +137,31 @@ DEV bool decode_item(const DevScene& S, const RenderParams& P, uint32_t item, It
   it.py = by * SOL_TILE + (pin >> 3);
   return it.px < S.width && it.py < S.height;  // false: padding pixel of an edge block
 }
+// The product kernel's order of the same items. A 16-sample item of a pixel inside glass can be 800 rays long, ~40 ms of one
+// lane's time, whatever else the GPU does: taken last it IS the tail of the launch (C5: 40 of 220 ms). So the blocks a counted
+// probe found heavy come first, block-major (all chunks of the heaviest block, then the next, ..), and the rest follows in
+// the chunk-major order of decode_item. Images do not depend on the order.
+DEV bool decode_item_ordered(const DevScene& S, const RenderParams& P, uint32_t item, Item& it) {
+  const uint32_t pair = item >> 6, pin = item & 63u;
+  const uint32_t heavy_pairs = S.n_first * P.n_chunks;
+  uint32_t k;
+  if (pair < heavy_pairs) {
+    k = pair / P.n_chunks;
+    it.chunk = pair - k * P.n_chunks;
+  } else {
+    const uint32_t q = pair - heavy_pairs, rest = P.n_local_blocks - S.n_first;
+    it.chunk = q / rest;
+    k = S.n_first + (q - it.chunk * rest);
+  }
+  const uint32_t lb = S.block_order ? S.block_order[k] : k;
+  it.slot = lb * 64u + pin;
+  const uint32_t b = lb * P.world + P.rank;
+  const uint32_t by = b / P.blocks_x, bx = b - by * P.blocks_x;
+  it.px = bx * SOL_TILE + (pin & 7u);
+  it.py = by * SOL_TILE + (pin >> 3);
+  return it.px < S.width && it.py < S.height;  // false: padding pixel of an edge block
+}
+
 // Writes a finished chunk sum: straight into the accumulator when the call has one chunk, else into the partial plane.
 DEV void write_chunk(const RenderParams& P, float* __restrict__ acc, float* __restrict__ partial, uint32_t slot, uint32_t chunk,
                      f3 sum) {

@@ -51,6 +51,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
   Path p = {};
   Trav t;
   t.cur = REF_DONE;
+  uint32_t item_rays0 = 0;  // (counted builds) ray count when the lane took its item
   __shared__ uint32_t reservoir[SOL_WG / 64][2];  // per wave: next reserved item, end of the reservation
   if (lane == 0) { reservoir[tid >> 6][0] = 0u; reservoir[tid >> 6][1] = 0u; }
 
@@ -69,6 +70,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
           if (s == s_end) {
             write_chunk(P, acc, partial, it.slot, it.chunk, sum);
             have_item = false;
+            if (COUNT && S.block_cost) atomicMax(S.block_cost + (it.slot >> 6), cnt.rays - item_rays0);  // the longest item decides
           }
         }
       }
@@ -93,12 +95,13 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         }
         const uint32_t item = my < left ? next + my : fresh + (my - left);
         if (item >= P.n_items) break;  // no work left for this lane
-        if (!decode_item(S, P, item, it)) continue;
+        if (!decode_item_ordered(S, P, item, it)) continue;
         s = P.first_sample + it.chunk * SOL_CHUNK;
         s_end = min(s + SOL_CHUNK, P.first_sample + P.n_samples);
         sum = mk3(0.f, 0.f, 0.f);
         have_item = true;
         alive = false;
+        if (COUNT) item_rays0 = cnt.rays;
       }
       if (!alive) {
         phase_tick<COUNT>(cnt, 2);

@@ -151,6 +151,12 @@ struct DevScene {
   float sphere_slack;  // half the fp32 box pad: tolerance of the sphere hit-point-in-own-box rule (sol_trace.h)
   float bgx, bgy, bgz;
   DCamera cam;
+  // Work order of the one-path-per-lane kernel (sol_path.h, decode_item_ordered): block_order[k] = local block taken k-th, the
+  // first n_first of them ("heavy": long paths, found by a counted probe at scene creation) with all their chunks up front;
+  // null = identity. block_cost: where a counted render records, per local block, the ray count of its longest item (null otherwise).
+  const uint32_t* block_order;
+  uint32_t n_first;
+  uint32_t* block_cost;
 };
 
 struct RenderParams {
