@@ -76,6 +76,27 @@ def test_tree_and_schedule_variants_are_bit_identical(env, monkeypatch):
         assert (got == want).all(), (name, env, int((got != want).sum()))
 
 
+def test_heavy_first_work_order_changes_nothing(monkeypatch):
+    """Scenes with long paths (glass) get their costly pixel blocks scheduled first (cost probe at scene creation,
+    sol_path.h decode_item_ordered); the frame must be the one of the plain order, for one rank and for a partition."""
+    sc = scenes.create_test_scene(RenderConfig(400, 200, 20))  # glass sphere: heavy blocks exist
+    want = None
+    for order in ("0", "1"):
+        monkeypatch.setenv("SOL_ORDER", order)
+        with DeviceScene(sc) as ds:
+            ds.render(0, 20, pu.SEED)
+            full = ds.read()
+            parts = []
+            for r in range(3):
+                ds.set_partition(r, 3)
+                ds.clear()
+                ds.render(0, 20, pu.SEED)
+                parts.append(ds.read())
+            merged = parts[0] + parts[1] + parts[2]  # sol_read writes 0 for the pixels of other ranks
+        want = full if want is None else want
+        assert (full == want).all() and (merged == want).all(), order
+
+
 def test_c5_shape_dielectric_metal_crop():
     """configs[4] shape: triangle mesh + dielectric and metal spheres; crop against the oracle."""
     assert_parity(_atrium_with_bsdfs(RenderConfig(640, 360, 16)), 16, rect=(256, 116, 384, 244))
