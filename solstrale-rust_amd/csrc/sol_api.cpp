@@ -12,6 +12,7 @@
 #include <limits>
 #include <string>
 #include <functional>
+#include <future>
 #include <map>
 #include <memory>
 #include <vector>
@@ -422,20 +423,28 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
       bin_list.clear();
       for (const char* p = bl; *p;) { bin_list.push_back(std::max(2, std::min(64, std::atoi(p)))); while (*p && *p != ',') ++p; if (*p) ++p; }
     }
+    // (the rebuilds are independent of each other: one host thread each)
+    std::vector<std::future<TreeCand>> jobs;
     for (int bins : bin_list) {
       const std::string name = "sah" + std::to_string(bins);
       if (want == "ref" || (!want.empty() && want != name)) continue;
-      TreeCand c;
-      c.name = name;
-      c.sah.reset(new SahBuilder());
-      c.sah->BINS = bins;
-      if (!c.sah->collect(tb.nodes, root_ref)) break;  // non-finite boxes or a single primitive: reference topology only
-      Box bx;
-      const uint32_t r = c.sah->build(0, c.sah->prims.size(), 0, bx);
-      c.wb.reset(new WideBuilder(c.sah->nodes, box_pad));
-      c.wroot = c.wb->build(SOL_REF_INDEX(r), 0);
-      c.depth = depth_of(*c.wb);
-      cands.push_back(std::move(c));
+      jobs.push_back(std::async(std::launch::async, [&, bins, name]() {
+        TreeCand c;
+        c.name = name;
+        c.sah.reset(new SahBuilder());
+        c.sah->BINS = bins;
+        if (!c.sah->collect(tb.nodes, root_ref)) return c;  // non-finite boxes or a single primitive: no rebuild (wb stays null)
+        Box bx;
+        const uint32_t r = c.sah->build(0, c.sah->prims.size(), 0, bx);
+        c.wb.reset(new WideBuilder(c.sah->nodes, box_pad));
+        c.wroot = c.wb->build(SOL_REF_INDEX(r), 0);
+        c.depth = depth_of(*c.wb);
+        return c;
+      }));
+    }
+    for (auto& j : jobs) {
+      TreeCand c = j.get();
+      if (c.wb) cands.push_back(std::move(c));
     }
     // drop what cannot run; a forced choice drops the rest
     std::vector<TreeCand> keep;
