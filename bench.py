@@ -65,7 +65,6 @@ def main():
                          "its throughput means nothing and the JSON line says so")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import __graft_entry__
     rank = int(os.environ.get("RANK", "0"))

@@ -3,7 +3,6 @@ world_size 2 and 3) and the inverse permutation. The pixel values come from the 
 image is a pure function of (scene, seed, pixel, sample): any partition reassembles to the single-rank image."""
 import os
 import socket
-import sys
 
 import numpy as np
 import pytest

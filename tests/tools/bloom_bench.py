@@ -2,7 +2,6 @@
 import _paths  # noqa: F401  (sys.path)
 import time
 
-import numpy as np
 import torch
 
 from solstrale_amd import DeviceScene, RenderConfig, scenes

@@ -1,7 +1,6 @@
 """Kernel time against samples per pixel (tail / fixed costs of a launch). Usage: python spp_curve.py [c3|c5] (not a pytest)"""
 import _paths  # noqa: F401  (sys.path)
 import sys
-import time
 
 import parity_util as pu
 from solstrale_amd import DeviceScene, RenderConfig, scenes
