@@ -177,6 +177,7 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
   uint32_t bin_root = root_ref;
   if (use_sah) { Box b; sah.BINS = use_sah > 1 ? std::min((int)SahBuilder::MAX_BINS, use_sah) : 16; bin_root = sah.build(0, sah.prims.size(), 0, b); }
   WideBuilder wb(use_sah ? sah.nodes : tb.nodes, box_pad);
+  wb.dp_collapse = !(std::getenv("SOL_COLLAPSE") && std::strcmp(std::getenv("SOL_COLLAPSE"), "greedy") == 0);
   const uint32_t wroot = wb.build(SOL_REF_INDEX(bin_root), 0);
   out->n_wide = (uint32_t)wb.out.size();
   out->depth = wb.max_depth;
@@ -414,6 +415,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
       TreeCand c;
       c.name = "ref";
       c.wb.reset(new WideBuilder(tb.nodes, box_pad));
+      c.wb->dp_collapse = !(std::getenv("SOL_COLLAPSE") && std::strcmp(std::getenv("SOL_COLLAPSE"), "greedy") == 0);
       c.wroot = c.wb->build(SOL_REF_INDEX(root_ref), 0);
       c.depth = depth_of(*c.wb);
       cands.push_back(std::move(c));
@@ -437,6 +439,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
         Box bx;
         const uint32_t r = c.sah->build(0, c.sah->prims.size(), 0, bx);
         c.wb.reset(new WideBuilder(c.sah->nodes, box_pad));
+        c.wb->dp_collapse = !(std::getenv("SOL_COLLAPSE") && std::strcmp(std::getenv("SOL_COLLAPSE"), "greedy") == 0);
         c.wroot = c.wb->build(SOL_REF_INDEX(r), 0);
         c.depth = depth_of(*c.wb);
         return c;

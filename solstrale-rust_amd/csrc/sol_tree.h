@@ -157,10 +157,86 @@ struct WideBuilder {
   }
   static float decode(float origin, uint32_t q, float scale) { return origin + (float)q * scale; }  // == device decode
 
+  // ---- which binary sub-trees become the (up to eight) children of a wide node ----
+  // GREEDY: open the inner child with the largest surface until eight children (or only leaves) remain.
+  // DP (Ylitie, Karras, Laine 2017, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", sec. 4.1):
+  //   the collapse of minimal surface-area cost. C(m, i) = cheapest way to represent binary sub-tree m with at most i child
+  //   slots of its parent: either as ONE wide node (its area x NODE_COST, its own eight slots distributed over its two
+  //   children) or by handing k slots to its left and i - k to its right sub-tree. The greedy rule leaves the many small
+  //   sub-trees near the leaves as wide nodes with two or three children: C3 has 92 075 nodes of 3.85 children on average
+  //   under it and 51 567 of 6.09 under the DP; node visits per ray 12.9 -> 11.9 (C3), 9.8 -> 9.5 (C2), time -0.5 .. -3 %.
+  bool dp_collapse = true;   // SOL_COLLAPSE=greedy selects the other rule (A/B)
+  static constexpr double NODE_COST = 2.5, PRIM_COST = 1.0;
+  struct Dp { double c[9]; uint8_t eff[9], split[9]; bool done = false; };
+  std::vector<Dp> dp;
+  static Box unite(const Box& a, const Box& b) {
+    Box r = a;
+    for (int k = 0; k < 3; ++k) { r.v[2 * k] = std::min(r.v[2 * k], b.v[2 * k]); r.v[2 * k + 1] = std::max(r.v[2 * k + 1], b.v[2 * k + 1]); }
+    return r;
+  }
+  double dp_t(uint32_t ref, const Box& box, int i) {
+    if (SOL_REF_KIND(ref) == SOL_REF_NODE) { dp_compute(SOL_REF_INDEX(ref)); return dp[SOL_REF_INDEX(ref)].c[i]; }
+    return PRIM_COST * (double)area(box);
+  }
+  void dp_compute(uint32_t m) {
+    if (dp.size() != bin.size()) dp.assign(bin.size(), Dp{});
+    Dp& d = dp[m];
+    if (d.done) return;
+    d.done = true;  // (a cycle cannot occur: TreeBuilder rejects them)
+    const DNode& n = bin[m];
+    const bool hl = SOL_REF_KIND(n.left) != SOL_REF_NONE, hr = SOL_REF_KIND(n.right) != SOL_REF_NONE;
+    for (int i = 0; i <= 8; ++i) { d.c[i] = 0.; d.eff[i] = 0; d.split[i] = 0; }
+    if (!hl && !hr) return;
+    if (hl != hr) {  // a single child: the node vanishes (eff 0 = pass through)
+      for (int i = 1; i <= 8; ++i) d.c[i] = hl ? dp_t(n.left, lbox(n), i) : dp_t(n.right, rbox(n), i);
+      dp[m] = d;
+      return;
+    }
+    const Box bl = lbox(n), br = rbox(n);
+    double tl[9], tr[9], dist[9];
+    for (int i = 1; i <= 8; ++i) { tl[i] = dp_t(n.left, bl, i); tr[i] = dp_t(n.right, br, i); }
+    Dp& e = dp[m];  // (dp may have been re-allocated? no: sized once above; re-take the reference after the recursion anyway)
+    for (int j = 2; j <= 8; ++j) {
+      dist[j] = std::numeric_limits<double>::infinity();
+      for (int k = 1; k < j; ++k)
+        if (tl[k] + tr[j - k] < dist[j]) { dist[j] = tl[k] + tr[j - k]; e.split[j] = (uint8_t)k; }
+    }
+    e.c[1] = NODE_COST * (double)area(unite(bl, br)) + dist[8];
+    e.eff[1] = 1;
+    for (int i = 2; i <= 8; ++i) {
+      if (dist[i] < e.c[i - 1]) { e.c[i] = dist[i]; e.eff[i] = (uint8_t)i; }
+      else { e.c[i] = e.c[i - 1]; e.eff[i] = e.eff[i - 1]; }
+    }
+  }
+  void dp_gather(uint32_t ref, const Box& box, int i, std::vector<Child>& c) {
+    if (SOL_REF_KIND(ref) == SOL_REF_NONE) return;
+    if (SOL_REF_KIND(ref) != SOL_REF_NODE) { c.push_back(Child{ref, box}); return; }
+    const uint32_t m = SOL_REF_INDEX(ref);
+    dp_compute(m);
+    const DNode& n = bin[m];
+    const int j = dp[m].eff[i];
+    if (j == 0) {  // pass through to the only child
+      if (SOL_REF_KIND(n.left) != SOL_REF_NONE) dp_gather(n.left, lbox(n), i, c); else dp_gather(n.right, rbox(n), i, c);
+    } else if (j == 1) {
+      c.push_back(Child{ref, box});  // a wide node of its own
+    } else {
+      const int k = dp[m].split[j];
+      dp_gather(n.left, lbox(n), k, c);
+      dp_gather(n.right, rbox(n), j - k, c);
+    }
+  }
+
   // Returns the reference to use for binary node `ni`: a wide node, or - when the node has a single child - that child.
   uint32_t build(uint32_t ni, uint32_t depth) {
     std::vector<Child> c;
     auto add = [&](uint32_t ref, const Box& b) { if (SOL_REF_KIND(ref) != SOL_REF_NONE) c.push_back(Child{ref, b}); };
+    if (dp_collapse) {
+      dp_compute(ni);
+      const DNode& n = bin[ni];
+      const bool hl = SOL_REF_KIND(n.left) != SOL_REF_NONE, hr = SOL_REF_KIND(n.right) != SOL_REF_NONE;
+      if (hl && hr) { const int k = dp[ni].split[8]; dp_gather(n.left, lbox(n), k, c); dp_gather(n.right, rbox(n), 8 - k, c); }
+      else { add(n.left, lbox(n)); add(n.right, rbox(n)); }
+    } else {
     add(bin[ni].left, lbox(bin[ni]));
     add(bin[ni].right, rbox(bin[ni]));
     while (c.size() < 8) {  // open the inner child with the largest surface until eight children (or only leaves) remain
@@ -179,6 +255,7 @@ struct WideBuilder {
       c.erase(c.begin() + best);
       add(n.left, lbox(n));
       add(n.right, rbox(n));
+    }
     }
     const uint32_t wi = (uint32_t)out.size();
     out.push_back(DWide{});
