@@ -3,23 +3,36 @@
 1080p/512spp, 1/2/4/8 GPU").
 
 A "step" is one pass of the hot path over one frame of synthetic input: the C3 workload (Sponza-class procedural atrium,
-262 267 triangles, 1920x1080, 512 spp per GPU), scene and BVH already resident in HBM when the timed region starts:
-    sol_clear -> sol_render (persistent path-tracing kernel + chunk resolve) -> gather of the per-rank tile accumulators to
-    rank 0 (RCCL over xGMI through torch.distributed when N > 1) -> sol_unpermute on rank 0.
-N ranks (one process per GPU, launched by torch.distributed.run) shard the 8x8-pixel tiles of the frame round-robin; the
-per-GPU work is fixed (each rank renders its tiles with 512*N spp), so scaling is "weak" and `value` is the whole-job
-aggregate Msamples/s = N * 1920*1080*512 / step time.
+262 267 triangles, 1920x1080, 512 spp), scene and BVH already resident in HBM when the timed region starts:
+    sol_clear -> sol_render (persistent path-tracing kernel + chunk resolve) -> sol_gather (N > 1: the per-rank tile
+    accumulators travel to rank 0 over RCCL/xGMI inside the C ABI; then the un-permute into the row-major image).
+N ranks (one process per GPU) shard the 8x8-pixel tiles of the frame round-robin. `python bench.py --gpus N` starts its own
+N rank processes (before any GPU call; a failed rank makes the run exit non-zero); under torch.distributed.run
+(RANK/WORLD_SIZE in the environment) it is one of the ranks. Two scaling modes:
+  --scaling strong (default: the metric's own definition - the SAME 1080p x 512 spp job on 1/2/4/8 GPUs): total work fixed;
+  --scaling weak: per-GPU work fixed (512*N spp on the shared frame).
+`value` is the whole-job aggregate Msamples/s = W*H*spp_total / step time (max over ranks).
 
 The JSON line also carries
-  roofline     : algorithmic bytes of the dominant kernel (sol_render_kernel) per launch / its HIP-event duration, against
-                 the 8 TB/s HBM peak (DESIGN.md "Measurement"; bytes per sample come from a counter-enabled run);
-  cpu_baseline : the f64 CPU restatement of the reference algorithm (oracle/, "port") timed on this box's host cores on a
-                 bounded sample of the same frame (rank 0, N=1 only).
+  roofline      : algorithmic bytes of the dominant kernel (sol_render_kernel) per launch / its HIP-event duration, against
+                  the 8 TB/s HBM peak (DESIGN.md "Measurement"; bytes per sample come from a counter-enabled run). NOTE: these
+                  bytes are served almost entirely by L1/L2/Infinity Cache - `frac` is the contract's algorithmic figure, not
+                  HBM utilisation; `traffic` (measured L2<->fabric bytes per launch, from rocprofv3 --pmc passes of this same
+                  run, N=1) and `traffic_frac` say what reaches the memory side;
+  roofline_valu : what actually bounds the kernel - vector-instruction issue x lane utilisation, from a PMC pass;
+  cpu_baseline  : the f64 CPU restatement of the reference algorithm (oracle/, "port") timed on this box's host cores on a
+                  bounded sample of the same frame (rank 0, N=1 only).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +41,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 SEED = 0x5017A1E
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_SIMD = 256 * 4
+KERNEL = "sol_render_kernel<false"  # the uncounted product kernel (probes at scene creation run the counted variant)
 
 
 def algorithmic_bytes(st, sizes):
@@ -50,33 +65,160 @@ def host_cores():
     return n
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (default: the workload's)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1: strong = the workload's total spp split by tiles over the ranks (default); weak = that spp per GPU")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel of the job (strong) / per GPU (weak); default: the workload's")
+    ap.add_argument("--obj", default="", help="render this OBJ (+MTL/textures beside it; e.g. the real sponza.obj) instead of the "
+                                              "procedural stand-in; config.workload then names the file")
+    ap.add_argument("--camera", default="", help="with --obj: fx,fy,fz,tx,ty,tz[,vfov] (look_from, look_at)")
+    ap.add_argument("--light", default="", help="with --obj: qx,qy,qz,ux,uy,uz,vx,vy,vz[,r,g,b] Quad light (corner, two edges)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic = null, no roofline_valu)")
+    ap.add_argument("--pmc-spp", type=int, default=64)
+    ap.add_argument("--no-build", action="store_true", help="do not run the build step (use under rocprofv3: no child processes)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dry run on a box with ONE GPU: every rank uses cuda:0, the gather goes through gloo on host "
                          "copies (RCCL refuses two ranks on one device); exercises partition, gather protocol and un-permute, "
                          "its throughput means nothing and the JSON line says so")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+# ---- N > 1 without a launcher: this process becomes the parent of N rank processes ----------------------------------------
+def launch_ranks(args):
+    """Starts N copies of this script, one per GPU, BEFORE anything here touches the GPU. Rank 0 prints the JSON line (its
+    stdout is ours); any rank failing fails the run (the others are terminated: a lost rank would hang their collectives)."""
+    if not args.no_build:
+        import __graft_entry__
+        __graft_entry__.build()  # once, here: the ranks must not race on the build (compiles and dlopens only, no GPU call)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--no-build"] + ["--no-build"]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in live:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ---- rocprofv3 --pmc passes of this same workload (N = 1) -------------------------------------------------------------------
+PMC_GROUPS = [  # FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: separate passes (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+    ["FETCH_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES"],
+    ["WRITE_SIZE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"],
+]
+
+
+def pmc_passes(args, spp):
+    """Runs this script under `rocprofv3 --pmc` (child processes; one pass per counter group, one timed launch of `spp` samples
+    per pixel each) and returns ({counter: sum over the product kernel's dispatches}, mean kernel ns) or (None, reason)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="solbench_pmc_")
+    counters, dur = {}, []
+    try:
+        for grp in PMC_GROUPS:
+            d = os.path.join(out, grp[0])
+            cmd = [rocprof, "--pmc"] + grp + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                                              os.path.abspath(__file__), "--workload", args.workload, "--spp", str(spp), "--steps", "1",
+                                              "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-build"]
+            if args.obj:
+                cmd += ["--obj", args.obj] + (["--camera", args.camera] if args.camera else []) + (["--light", args.light] if args.light else [])
+            try:
+                r = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()),
+                                   capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 pass {grp[0]} timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 pass {grp[0]} failed (rc {r.returncode}): {(r.stderr or '')[-300:]}"
+            seen = set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if KERNEL not in row["Kernel_Name"]:
+                        continue
+                    counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    if (grp[0], row["Dispatch_Id"]) not in seen:
+                        seen.add((grp[0], row["Dispatch_Id"]))
+                        dur.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+            if not seen:
+                return None, f"rocprofv3 pass {grp[0]}: no dispatch of {KERNEL} in the output"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    return counters, sum(dur) / len(dur)
+
+
+def make_scene(args, spp_total):
+    from solstrale_amd import RenderConfig, scenes
+    wl = args.workload
+    w, h, spp0 = {"c1": (400, 400, 50), "c2": (1920, 1080, 256), "c3": (1920, 1080, 512), "c4": (3840, 2160, 1024),
+                  "c5": (1920, 1080, 2048)}[wl]
+    if args.obj:
+        cam = light = None
+        if args.camera:
+            c = [float(x) for x in args.camera.split(",")]
+            cam = (c[0:3], c[3:6], c[6] if len(c) > 6 else 55.)
+        if args.light:
+            l = [float(x) for x in args.light.split(",")]
+            light = (l[0:3], l[3:6], l[6:9], tuple(l[9:12]) if len(l) >= 12 else (18., 17., 15.))
+        make = lambda rc: scenes.obj_file_scene(args.obj, rc, cam, light)
+        name = f"{wl.upper()} shape ({w}x{h}) on the supplied OBJ file {os.path.basename(args.obj)} (host OBJ+MTL loader), 1 quad light + sky"
+    elif wl in ("c3", "c4"):
+        name = (f"{wl.upper()} Sponza-class procedural atrium (stand-in: the real sponza.obj is not available offline; --obj takes one), "
+                f"{scenes.SPONZA_TRIANGLES} triangles, 24 Lambertian materials (8 image-textured), 1 quad light + sky")
+        make = lambda rc: scenes.sponza_like(rc)
+    elif wl == "c5":
+        name = f"C5 statue-class displaced mesh (stand-in), ~{scenes.STATUE_TRIANGLES} triangles, Metal(0.1) + Dielectric(1.5), 1 quad light"
+        make = lambda rc: scenes.statue_like(rc)
+    elif wl == "c2":
+        name = "C2 Cornell box + 10000 Lambertian spheres"
+        make = lambda rc: scenes.cornell_spheres(rc)
+    else:
+        name = "C1 Cornell box (18 quads)"
+        make = lambda rc: scenes.cornell_box(rc)
+    return w, h, spp0, name, make
+
+
+def worker(args):
     import torch
     import __graft_entry__
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if rank == 0:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if rank == 0 and not args.no_build:
         __graft_entry__.build()
     import torch.distributed as dist
     if args.rehearse:
         local_rank = 0
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -84,53 +226,42 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            rccl_ranks = dist.get_world_size()
         dist.barrier()
-    if rank != 0:
+    if rank != 0 and not args.no_build:
         __graft_entry__.build()  # no-op when up to date; loads the libraries
-    from solstrale_amd import DeviceScene, RenderConfig, device_count, record_sizes, scenes, tiles
+    from solstrale_amd import DeviceScene, RenderConfig, comm_unique_id, device_count, record_sizes, tiles
     if device_count() < 1:
         raise SystemExit("bench.py: no HIP device; the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    if args.workload == "c3":
-        w, h, spp0 = 1920, 1080, 512
-        name = f"C3 Sponza-class procedural atrium, {scenes.SPONZA_TRIANGLES} triangles, 24 Lambertian materials (8 image-textured), 1 quad light"
-        make = lambda rc: scenes.sponza_like(rc)
-    elif args.workload == "c4":  # configs[3]: C3's scene at 4K, 1024 spp over 8 GPUs = 128 spp of per-GPU work
-        w, h, spp0 = 3840, 2160, 128
-        name = f"C4 Sponza-class procedural atrium, {scenes.SPONZA_TRIANGLES} triangles, 4K (BASELINE: 1024 spp over 8 GPUs = 128 spp per GPU)"
-        make = lambda rc: scenes.sponza_like(rc)
-    elif args.workload == "c5":  # configs[4]: 2048 spp over 8 GPUs = 256 spp of per-GPU work
-        w, h, spp0 = 1920, 1080, 256
-        name = f"C5 statue-class displaced mesh, ~{scenes.STATUE_TRIANGLES} triangles, Metal(0.1) + Dielectric(1.5), 1 quad light (BASELINE: 2048 spp over 8 GPUs = 256 spp per GPU)"
-        make = lambda rc: scenes.statue_like(rc)
-    elif args.workload == "c2":
-        w, h, spp0 = 1920, 1080, 256
-        name = "C2 Cornell box + 10000 Lambertian spheres"
-        make = lambda rc: scenes.cornell_spheres(rc)
-    else:
-        w, h, spp0 = 400, 400, 50
-        name = "C1 Cornell box (18 quads)"
-        make = lambda rc: scenes.cornell_box(rc)
-    spp_gpu = args.spp or spp0
-    spp = spp_gpu * world  # weak scaling: per-GPU work fixed
+    w, h, spp0, name, make = make_scene(args, 0)
+    spp_arg = args.spp or spp0
+    spp = spp_arg * world if args.scaling == "weak" else spp_arg  # samples per pixel of the whole job
     t0 = time.time()
     scene = make(RenderConfig(w, h, spp))
     t_build = time.time() - t0
     t0 = time.time()
     ds = DeviceScene(scene, local_rank)
     t_upload = time.time() - t0
-    ds.set_partition(rank, world)
+    bt = ds.build_times()
     stream = torch.cuda.current_stream(dev)
     ds.set_stream(stream.cuda_stream)
+    use_abi_gather = world > 1 and not args.rehearse
+    if use_abi_gather:
+        # the communicator lives behind the C ABI (sol_comm_init); torch.distributed only ships the 128-byte id
+        box = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ds.comm_init(rank, world, box[0])
+    else:
+        ds.set_partition(rank, world)
     n_acc = ds.accum_floats()
     acc = torch.zeros(n_acc, dtype=torch.float32, device=dev)
     ds.bind_accum(acc.data_ptr(), n_acc)
     image = torch.empty(h * w * 3, dtype=torch.float32, device=dev) if rank == 0 else None
     ds.kernel_timing(True)
-    # a sol_render call handles at most ~4e9 work items; split the sample range if needed
-    max_spp_call = max(16, (0xFFFF0000 // max(1, n_acc // 3)) * 16)
+    max_spp_call = max(16, ds.max_samples_per_call() // 16 * 16)  # a sol_render call handles < 2^32 work items
 
     def step():
         ds.clear()
@@ -139,14 +270,17 @@ def main():
             n = min(spp - f, max_spp_call)
             ds.render(f, n, SEED)
             f += n
-        if args.rehearse and world > 1:
+        if use_abi_gather:
+            ds.gather(image.data_ptr() if rank == 0 else 0)
+        elif world > 1:  # rehearsal: gloo through host copies
             torch.cuda.synchronize(dev)
             g = tiles.gather_to_rank0(acc.cpu(), world, rank)
-            gathered = g.to(dev) if rank == 0 else None
+            if rank == 0:
+                gathered = g.to(dev)
+                ds.unpermute(gathered.data_ptr(), world, image.data_ptr())
+                torch.cuda.synchronize(dev)
         else:
-            gathered = tiles.gather_to_rank0(acc, world, rank)
-        if rank == 0:
-            ds.unpermute(gathered.data_ptr(), world, image.data_ptr())
+            ds.gather(image.data_ptr())
 
     def fence():
         if world > 1:
@@ -161,11 +295,12 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (args.rehearse or world == 1) else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    k_ms, grid = ds.last_kernel_ms()  # duration of the last step's render kernel (HIP events on its stream)
+    k_ms, grid = ds.last_kernel_ms()  # duration of the last step's (last) render kernel (HIP events on its stream)
+    last_call_spp = spp - (spp - 1) // max_spp_call * max_spp_call
 
     # ---- counters: exact per-sample algorithmic bytes and rays from a counter-enabled run of the same kernels ----
     ds.bind_accum(0, 0)
@@ -177,50 +312,84 @@ def main():
     sizes = record_sizes()
     bytes_per_sample = algorithmic_bytes(st, sizes) / st["samples"]
     rays_per_sample = st["rays"] / st["samples"]
-    local_samples = st["samples"] // c_spp * spp  # samples this rank renders per step
+    launch_samples = st["samples"] // c_spp * last_call_spp  # samples of the launch k_ms belongs to (this rank)
 
     out = None
     if rank == 0:
         total_samples = float(w) * h * spp
         ms_per_step = dt / args.steps * 1e3
         value = total_samples / (dt / args.steps) / 1e6
-        achieved = bytes_per_sample * local_samples / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                tj = json.load(open(tf))
-                # measured L2<->fabric bytes per sample (profiles/, separate rocprofv3 --pmc passes) x this launch's samples
-                if args.workload == "c3" and "_bytes_per_sample" in tj:
-                    traffic = int(tj["_bytes_per_sample"] * local_samples)
-            except Exception:
-                traffic = None
+        achieved = bytes_per_sample * launch_samples / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "width": w, "height": h, "spp_per_gpu": spp_gpu, "spp_total": spp, "seed": SEED,
-                       "max_depth": 50, "sharding": f"8x8 tiles round-robin over {world} rank(s), gather to rank 0"},
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": args.scaling,  # (at N = 1 both modes are the same job)
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.obj else "user-supplied OBJ",
+            "config": {"workload": name, "width": w, "height": h, "spp_total": spp, "pixel_samples_per_gpu": int(w * h * spp // world),
+                       "seed": SEED, "max_depth": 50, "scaling_mode": args.scaling,
+                       "sharding": f"8x8 tiles round-robin over {world} rank(s); every rank renders its tiles with all {spp} spp; "
+                                   f"gather to rank 0 " + ("inside the C ABI (sol_gather: grouped ncclSend/ncclRecv)" if use_abi_gather else
+                                                           "(rehearsal: gloo)" if world > 1 else "(single rank: un-permute only)")},
             "mrays_per_s": round(value * rays_per_sample, 2),
             "rays_per_sample": round(rays_per_sample, 4),
+            "rays_per_sample_note": "the open-roofed atrium ends most paths on the sky after ~3 rays; a closed interior costs several "
+                                    "times more rays per sample - Mrays/s is the figure that transfers between scenes",
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "traffic_source": None,
+                         "frac_note": "ALGORITHMIC bytes (every node / primitive / texel record the search touches) per second; they are "
+                                      "served by L1/L2/Infinity Cache, so this is NOT HBM utilisation - see traffic_frac and roofline_valu",
                          "kernel": "sol_render_kernel", "kernel_ms": round(k_ms, 3), "grid_blocks": grid,
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
-                         "samples_per_launch": int(local_samples),
+                         "samples_per_launch": int(launch_samples),
                          "counters_per_sample": {k: round(v / st["samples"], 4) for k, v in st.items() if k not in ("samples", "max_stack")}},
-            "setup_s": {"scene_and_bvh_build": round(t_build, 2), "upload": round(t_upload, 2)},
+            "setup_s": {"scene_and_bvh_build_host": round(t_build, 2), "sol_scene_create": round(t_upload, 2),
+                        **{"create_" + k: round(v, 3) for k, v in bt.items()}},
         }
+        if world > 1:
+            out["rccl_ranks"] = rccl_ranks
         if args.rehearse:
             out["rehearsal"] = "all ranks on cuda:0, gloo gather through host copies: not a measurement"
             # the assembled frame must equal what one rank renders alone (the image is a pure function of scene and seed)
             ds.set_partition(0, 1)
-            ds.bind_accum(0, 0)
             ds.clear()
-            ds.render(0, min(spp, 32), SEED)
+            ds.render(0, min(spp, 64), SEED)
             single = torch.from_numpy(ds.read()).to(dev).reshape(-1)
             ds.set_partition(rank, world)
-            out["rehearsal_frame_check"] = "skipped (spp > 32)" if spp > 32 else bool(torch.equal(single, image))
+            out["rehearsal_frame_check"] = "skipped (spp > 64)" if spp > 64 else bool(torch.equal(single, image))
+    ds.close()
+    del ds
+    if rank == 0 and world == 1 and not args.no_pmc:
+        p_spp = min(args.pmc_spp, spp)
+        counters, info = pmc_passes(args, p_spp)
+        rf = out["roofline"]
+        if counters is None:
+            rf["traffic_source"] = f"not measured: {info}"
+        else:
+            p_samples = launch_samples / last_call_spp * p_spp
+            g = counters.get
+            # FETCH_SIZE / WRITE_SIZE are KiB at the L2<->fabric boundary (Infinity-Cache hits included); gfx950 tallies a
+            # 128-B read request as 64 B: reads x2 (guide, "HBM")
+            fabric_per_sample = (g("FETCH_SIZE", 0.0) * 2048.0 + g("WRITE_SIZE", 0.0) * 1024.0) / p_samples
+            rf["traffic"] = int(fabric_per_sample * launch_samples)
+            rf["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes of this run's workload at "
+                                    f"{p_spp} spp, scaled per sample to this launch; L2<->fabric bytes, Infinity-Cache hits included")
+            rf["traffic_frac"] = round(rf["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)
+            clock = g("GRBM_GUI_ACTIVE", 0.0) / 8.0 / (info * 1e-9) if g("GRBM_GUI_ACTIVE") else 2.4e9
+            k_cycles = info * 1e-9 * clock
+            lane_util = g("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, g("SQ_ACTIVE_INST_VALU", 0.0) * 64.0)
+            # SQ_* cycle counters count quad-cycles: ACTIVE_INST_VALU x 4 = cycles in which some wave executes a vector instruction;
+            # one SIMD accepts at most one wave64 vector instruction per 4 cycles from a single wave and 2 cycles overall (SIMD-32)
+            busy4 = g("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (N_SIMD * k_cycles)
+            inst_per_s = g("SQ_INSTS_VALU", 0.0) / (info * 1e-9)
+            peak_inst = N_SIMD * clock / 2.0
+            out["roofline_valu"] = {
+                "bound": "valu_issue", "achieved": round(inst_per_s * lane_util / 1e9, 2), "peak": round(peak_inst / 1e9, 2),
+                "unit": "G wave64-instr/s x lane utilisation", "frac": round(inst_per_s * lane_util / peak_inst, 5),
+                "valu_instr_per_sample": round(g("SQ_INSTS_VALU", 0.0) / p_samples, 1), "lane_utilisation": round(lane_util, 4),
+                "issue_busy_at_4_cycles_per_instr": round(busy4, 4), "issue_frac_of_2_cycle_peak": round(inst_per_s / peak_inst, 4),
+                "wave_cycles_waiting_frac": round(g("SQ_WAIT_ANY", 0.0) / max(1.0, g("SQ_WAVE_CYCLES", 0.0)), 4),
+                "clock_ghz": round(clock / 1e9, 3), "kernel_ms_under_pmc": round(info * 1e-6, 3), "pmc_spp": p_spp}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             import orc  # TEST INFRASTRUCTURE, used here only as the timed CPU baseline
             t0 = time.time()
@@ -237,10 +406,16 @@ def main():
                                              f"reference algorithm (reference-order BVH search, no culling), row-parallel std::thread",
                                    "mrays_per_s": round(ost["rays"] / tc / 1e6, 3), "gpu_over_cpu": round(value / cpu_v, 1)}
         print(json.dumps(out), flush=True)
-    ds.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -196,10 +196,61 @@ int sol_device_count(void);
 int sol_scene_create(const SolSceneDesc* desc, int device, SolScene** out);
 void sol_scene_destroy(SolScene* scene);
 
+/* Creation options (no reference analogue: the reference has one BVH builder and no scheduler to tune). All-zero = the
+ * defaults of sol_scene_create. The SOL_* environment variables of DESIGN.md 9 remain developer overrides, read once here. */
+#define SOL_TREE_AUTO 0    /* candidates on the host + counted probe renders on the device pick one (default)        */
+#define SOL_TREE_REF 1     /* the reference's topology (src/hittable/bvh.rs:84-162), collapsed 8-wide                 */
+#define SOL_TREE_SAH8 2    /* host binned-SAH rebuild, 8 / 16 / 64 bins                                              */
+#define SOL_TREE_SAH16 3
+#define SOL_TREE_SAH64 4
+#define SOL_TREE_DEVICE 5  /* built on the GPU (LBVH + 8-wide collapse kernels, sol_build.hip)  */
+typedef struct SolCreateOptions {
+  uint32_t size;            /* sizeof(SolCreateOptions): lets the struct grow                                         */
+  int32_t world_tree;       /* SOL_TREE_*                                                                              */
+  int32_t no_work_order_probe; /* 1: skip the 4-spp cost probe of the frame (heavy-first work order); for previews     */
+  int32_t reserved[5];
+} SolCreateOptions;
+int sol_scene_create_ex(const SolSceneDesc* desc, int device, const SolCreateOptions* options, SolScene** out);
+/* Seconds sol_scene_create spent in: [0] host tree candidates, [1] uploads, [2] device tree build, [3] probe renders. */
+int sol_scene_build_times(const SolScene* scene, double out[4]);
+
+/* Scheduler options of a live handle (take effect at the next sol_render; results never depend on them). */
+#define SOL_OPT_SWITCH_BELOW 1        /* 0..64: a wave leaves the search loop when fewer 64ths of its lanes search      */
+#define SOL_OPT_MAX_BLOCKS_PER_CU 2   /* 0 = as many as fit; n >= 1 caps resident workgroups per CU (occupancy studies)  */
+#define SOL_OPT_KERNEL 3              /* 0 auto, 1 one-path-per-lane (product), 2 / 3 wavefront variants (A/B only)      */
+#define SOL_OPT_WORK_ORDER 4          /* 0: plain chunk-major order, 1: heavy-first order from the creation probe        */
+int sol_scene_set_option(SolScene* scene, int option, int64_t value);
+
 /* Image-tile sharding for one-process-per-GPU runs (no reference analogue). The image is cut
  * into 8x8-pixel blocks, block b (row-major) belongs to rank b % world. Each rank accumulates only its own
  * blocks in a compact buffer of sol_accum_floats() floats: [local_block][py][px][rgb]. Default rank 0/1. */
 int sol_scene_set_partition(SolScene* scene, int rank, int world);
+/* A caller-bound accumulator (sol_scene_bind_accum) whose size would change makes this fail with SOL_EINVAL: unbind
+ * (sol_scene_bind_accum(scene, NULL, 0)) first, re-bind a buffer of the new sol_accum_floats() afterwards. */
+
+/* Multi-GPU behind the ABI ("the handle owns the communicators, the read gathers across GPUs"). One
+ * process per GPU, each with its own SolScene of the same description:
+ *   rank 0:  sol_comm_unique_id(id)  -> ship the 128 bytes to the other ranks by any means (file, socket, MPI, ..)
+ *   all:     sol_comm_init(scene, rank, world, id)   collective: ncclCommInitRank (RCCL); also sets the tile partition
+ *   all:     sol_render(...)         every rank renders the 8x8 tiles it owns
+ *   all:     sol_gather(scene, image_dev)            collective, asynchronous on the scene's stream: the compact fp32
+ *            accumulators travel to rank 0 (grouped ncclSend / ncclRecv: every shard rides its own xGMI link into the
+ *            root, no ring) and are un-permuted there into `image_dev` (device, W*H*3 floats, row 0 = top; NULL = the
+ *            scene's own image buffer, see sol_resolve_image); ranks != 0 ignore image_dev.
+ *   rank 0:  sol_read_image(scene, host_rgb_sum)     blocks; copies the gathered image out (or use the device pointer)
+ *   all:     sol_comm_destroy(scene)  (also done by sol_scene_destroy)
+ * RCCL (librccl.so) is loaded on the first sol_comm_* call; a single-GPU process never needs it. */
+#define SOL_UNIQUE_ID_BYTES 128
+int sol_comm_unique_id(uint8_t id[SOL_UNIQUE_ID_BYTES]);
+int sol_comm_init(SolScene* scene, int rank, int world, const uint8_t id[SOL_UNIQUE_ID_BYTES]);
+int sol_comm_destroy(SolScene* scene);
+int sol_gather(SolScene* scene, void* image_dev);
+/* Diagnostic for single-GPU boxes: sends the accumulator to this very rank through the communicator (the grouped
+ * ncclSend / ncclRecv pair sol_gather uses) and compares the bytes. */
+int sol_comm_self_check(SolScene* scene);
+int sol_read_image(SolScene* scene, float* rgb_sum);
+/* Largest n_samples one sol_render call accepts for the current partition (the work counter is 32 bits). */
+uint32_t sol_max_samples_per_call(const SolScene* scene);
 
 /* Compact accumulator (device memory, fp32 sums over samples). By default the handle owns it; a caller that
  * wants to hand it to a collective (torch.distributed / RCCL) may bind its own device buffer instead. */
@@ -297,7 +348,7 @@ int sol_last_kernel_ms(SolScene* scene, float* ms, uint32_t* grid_blocks);
 /* Function-level evaluation of the device code on n rows of host floats (in_stride / out_stride floats per row), for
  * pinning the fp32 arithmetic contract bit for bit (tests/test_gpu_functions.py). fn: 0 arithmetic, 1 elementary
  * functions, 2 RNG, 3 vector ops + Onb::new, 4 Sphere::hit, 5 Quad::hit, 6 Triangle::hit, 7 Aabb::hit, 8 sampling
- * (row layouts: solstrale-rust_amd/csrc/sol_kernels.hip, sol_eval_kernel). No reference analogue. */
+ * (row layouts: solstrale-rust_amd/csrc/sol_aux.hip, sol_eval_kernel). No reference analogue. */
 int sol_eval(int device, uint32_t fn, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride);
 
 /* Sizes of the device records, for the algorithmic-bytes formula: node, sphere, quad, triangle

@@ -4,23 +4,26 @@
   libsolstrale_host.so  C++ host mirror of the reference's Scene / ray_trace surface          (g++)
 
 hipcc cross-compiles gfx950 code objects without a GPU. -ffp-contract=off keeps the device arithmetic the plain
-IEEE sequence the parity tests pin (DESIGN.md "fp32 arithmetic contract").
+IEEE sequence the parity tests pin (DESIGN.md "fp32 arithmetic contract"). Translation units are compiled in
+parallel to objects (only the stale ones) and linked; `build(out_dir=..., extra_hip_flags=...)` makes an A/B variant
+of the device library elsewhere (tests/tools/variants.py), selected at run time through SOLSTRALE_BUILD_DIR.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 BUILD = os.path.join(HERE, "_build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 HIP_SRC = ["csrc/sol_render.hip", "csrc/sol_wavefront.hip", "csrc/sol_aux.hip", "csrc/sol_api.cpp"]
-HIP_DEPS = HIP_SRC + ["csrc/sol_types.h", "csrc/sol_math.h", "csrc/sol_trace.h", "csrc/sol_shade.h", "csrc/sol_path.h", "csrc/sol_launch.h", "csrc/sol_tree.h",
-                      "../include/solstrale_hip.h"]
+HIP_HDR = ["csrc/sol_types.h", "csrc/sol_math.h", "csrc/sol_trace.h", "csrc/sol_shade.h", "csrc/sol_path.h", "csrc/sol_launch.h",
+           "csrc/sol_tree.h", "../include/solstrale_hip.h"]
 HOST_SRC = ["host/solstrale_host.cpp", "host/solstrale_obj.cpp", "host/solstrale_host_c.cpp"]
 HOST_DEPS = HOST_SRC + ["host/solstrale.hpp", "../include/solstrale_hip.h", "../include/solstrale_host.h"]
 
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
              "-Wall", "-Wno-unused-value"]
 
 
@@ -36,15 +39,30 @@ def _run(cmd):
     subprocess.check_call(cmd, cwd=HERE)
 
 
-def build(force=False, extra_hip_flags=()):
-    os.makedirs(BUILD, exist_ok=True)
-    hip_lib = os.path.join(BUILD, "libsolstrale_hip.so")
-    host_lib = os.path.join(BUILD, "libsolstrale_host.so")
-    if force or _stale(hip_lib, HIP_DEPS + ["build.py"]):
-        _run([HIPCC] + HIP_FLAGS + list(extra_hip_flags) + HIP_SRC + ["-o", hip_lib])
+def build(force=False, extra_hip_flags=(), out_dir=None):
+    out_dir = out_dir or BUILD
+    os.makedirs(out_dir, exist_ok=True)
+    hip_lib = os.path.join(out_dir, "libsolstrale_hip.so")
+    host_lib = os.path.join(out_dir, "libsolstrale_host.so")
+    flags_file = os.path.join(out_dir, "hip_flags.txt")
+    flags = HIP_FLAGS + list(extra_hip_flags)
+    if not os.path.exists(flags_file) or open(flags_file).read() != " ".join(flags):
+        force = True
+    jobs, objs = [], []
+    for src in HIP_SRC:
+        obj = os.path.join(out_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + HIP_HDR + ["build.py"]):
+            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(_run, jobs))
+        open(flags_file, "w").write(" ".join(flags))
+    if jobs or not os.path.exists(hip_lib):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", hip_lib, "-ldl"])
     if force or _stale(host_lib, HOST_DEPS + ["build.py"]) or os.path.getmtime(hip_lib) > os.path.getmtime(host_lib):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-pthread"] + HOST_SRC +
-             ["-o", host_lib, "-L" + BUILD, "-lsolstrale_hip", "-Wl,-rpath,$ORIGIN"])
+             ["-o", host_lib, "-L" + out_dir, "-lsolstrale_hip", "-Wl,-rpath,$ORIGIN"])
     return hip_lib, host_lib
 
 

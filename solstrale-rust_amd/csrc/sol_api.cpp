@@ -1,9 +1,12 @@
 // sol_api.cpp -- implementation of the C ABI (include/solstrale_hip.h): validation of the flattened scene,
-// conversion to the fp32 device layout (sol_types.h), upload, and launches of the kernels in sol_kernels.hip.
+// conversion to the fp32 device layout (sol_types.h), upload, and launches of the kernels in sol_render.hip / sol_wavefront.hip / sol_aux.hip / sol_build.hip.
 // There is NO CPU fallback: without a HIP device every compute entry point fails with SOL_EDEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen-ed on the first sol_comm_* call
+#include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +18,7 @@
 #include <future>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/solstrale_hip.h"
@@ -55,6 +59,8 @@ int upload(const std::vector<T>& host, T** dev) {
 
 }  // namespace
 
+#define SOL_MAX_ITEMS 0xFF000000ull
+
 struct SolScene {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -89,6 +95,11 @@ struct SolScene {
   uint32_t wf_slots = 4u << 20;       // SOL_WF_SLOTS: pool size of the two-kernel wavefront
   uint32_t wf_min_items = 2u << 20;   // SOL_WF_MIN_ITEMS: jobs below this use the single-launch kernel
   uint32_t last_rounds = 0; int last_version = 0;
+  double build_times[4] = {0., 0., 0., 0.};  // sol_scene_build_times
+  bool order_enabled = true;         // SOL_OPT_WORK_ORDER
+  int max_bpc = 0;                   // SOL_OPT_MAX_BLOCKS_PER_CU (0 = what the occupancy query allows)
+  // multi-GPU (sol_comm_init): RCCL communicator of the tile partition and rank 0's receive buffer
+  void* comm = nullptr; float* gathered = nullptr; size_t gathered_floats = 0;
   bool timing = false;  // sol_kernel_timing: HIP events around the render kernel on its own stream
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   uint32_t timed_launches = 0, last_grid = 0;
@@ -100,7 +111,7 @@ static int rebuild_order(SolScene* s) {
   s->S.block_order = nullptr;
   s->S.n_first = 0;
   const uint32_t n = s->n_local_blocks;
-  if (s->block_cost.empty() || n < 2) return SOL_OK;
+  if (!s->order_enabled || s->block_cost.empty() || n < 2) return SOL_OK;
   std::vector<uint32_t> cost(n);
   double sum = 0.;
   for (uint32_t lb = 0; lb < n; ++lb) {
@@ -136,7 +147,7 @@ static int set_partition(SolScene* s, int rank, int world) {
   // every rank's compact buffer has the size of rank 0's (the largest) so that a gather has equal counts
   const uint32_t max_blocks = (nb + (uint32_t)world - 1u) / (uint32_t)world;
   size_t floats = (size_t)max_blocks * 64u * 3u;
-  if (floats != s->acc_floats || !s->acc) {
+  if (floats != s->acc_floats || !s->acc_own) {
     if (s->acc_own) { hipFree(s->acc_own); s->acc_own = nullptr; }
     HIP_TRY(hipMalloc((void**)&s->acc_own, std::max<size_t>(floats * sizeof(float), 64)));
     HIP_TRY(hipMemset(s->acc_own, 0, std::max<size_t>(floats * sizeof(float), 64)));
@@ -242,6 +253,7 @@ void sol_scene_destroy(SolScene* s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
+  sol_comm_destroy(s);
   void* ptrs[] = {s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
                   s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters, s->pool, s->queue, s->wf_ctr,
                   s->bloom_a, s->bloom_b, s->bloom_w, s->aux[0], s->aux[1], s->dscene, s->order_dev};
@@ -254,9 +266,19 @@ void sol_scene_destroy(SolScene* s) {
   delete s;
 }
 
-int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
+int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) { return sol_scene_create_ex(d, device, nullptr, out); }
+
+int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOptions* opt_in, SolScene** out) {
   if (!d || !out) return fail(SOL_EINVAL, "null argument");
   *out = nullptr;
+  SolCreateOptions opt{};
+  if (opt_in) {
+    if (opt_in->size < 8 || opt_in->size > 4096) return fail(SOL_EINVAL, "SolCreateOptions.size %u", opt_in->size);
+    std::memcpy(&opt, opt_in, std::min<size_t>(opt_in->size, sizeof opt));
+  }
+  if (opt.world_tree < SOL_TREE_AUTO || opt.world_tree > SOL_TREE_DEVICE) return fail(SOL_EINVAL, "bad world_tree option %d", opt.world_tree);
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto seconds_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   if (d->abi_version != SOL_ABI_VERSION) return fail(SOL_EINVAL, "abi_version %u, expected %u", d->abi_version, SOL_ABI_VERSION);
   if (d->width < 2 || d->height < 2 || (uint64_t)d->width * d->height > 0x3FFFFFFFull) return fail(SOL_EINVAL, "bad image size %ux%u", d->width, d->height);
   if (d->shader_kind > SOL_SHADER_SIMPLE) return fail(SOL_EINVAL, "bad shader kind %u", d->shader_kind);
@@ -407,8 +429,9 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   std::vector<TreeCand> cands;
   auto depth_of = [&](const WideBuilder& w) { return (SOL_WORLD_BINARY ? world_depth : 7u * w.max_depth) + medium_depth + 2; };
   const uint32_t stack_limit = SOL_LDS_STACK + SOL_SPILL_STACK;
-  const char* bvh_env = std::getenv("SOL_BVH");
-  const std::string want = bvh_env ? (std::strcmp(bvh_env, "sah") == 0 ? "sah16" : bvh_env) : "";
+  const char* bvh_env = std::getenv("SOL_BVH");  // developer override of SolCreateOptions.world_tree
+  static const char* const tree_names[] = {"", "ref", "sah8", "sah16", "sah64", "device"};
+  const std::string want = bvh_env ? (std::strcmp(bvh_env, "sah") == 0 ? "sah16" : bvh_env) : tree_names[opt.world_tree];
   uint32_t wroot = root_ref;
   if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) {
     {
@@ -471,6 +494,8 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   const std::vector<DWide>& wides0 = cands.empty() ? no_wides : cands[0].wb->out;
   uint32_t tree_depth = cands.empty() ? medium_depth + 2 : cands[0].depth;
 
+  const double t_host_trees = seconds_since(t_begin);
+
   // ---- lights ----
   std::vector<uint32_t> lights(d->lights, d->lights + d->n_lights);
   for (uint32_t i = 0; i < d->n_lights; ++i) {
@@ -486,6 +511,8 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   HIP_TRY(hipSetDevice(device));
   SolScene* s = new SolScene();
   s->device = device;
+  s->build_times[0] = t_host_trees;
+  const auto t_upload0 = std::chrono::steady_clock::now();
   struct Cleanup { SolScene* s; bool keep = false; ~Cleanup() { if (!keep) sol_scene_destroy(s); } } cleanup{s};
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -504,6 +531,8 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   HIP_TRY(hipMemset(s->counters, 0, sizeof(DevCounters)));
   HIP_TRY(hipMalloc((void**)&s->image, (size_t)d->width * d->height * 3 * sizeof(float)));
   HIP_TRY(hipMalloc((void**)&s->rgb8, (size_t)d->width * d->height * 3));
+  s->build_times[1] = seconds_since(t_upload0);
+  const auto t_probe0 = std::chrono::steady_clock::now();
 
   DevScene& S = s->S;
   S.nodes = s->nodes; S.wides = s->wides; S.wroot = wroot; S.tris = s->tris; S.tri_shade = s->tri_shade; S.quads = s->quads; S.spheres = s->spheres;
@@ -530,6 +559,7 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
   // 0: 29.2 / 162.9 / 236.7 / 25.9, 8: 27.7 / 124.3 / 193.1 / 25.5, 16: 27.5 / 111.8 / 186.9 / 25.6, 24: 28.6 / 108.6 / 192.3 / 26.8.
   s->switch_below = 16u;
   if (const char* ps = std::getenv("SOL_SWITCH")) s->switch_below = (uint32_t)std::min(64, std::max(0, std::atoi(ps)));
+  if (const char* mb = std::getenv("SOL_MAX_BPC")) s->max_bpc = std::max(0, std::atoi(mb));  // occupancy experiments
   if (const char* ps = std::getenv("SOL_POOL_SLOTS")) s->pool_slots_override = (uint32_t)std::atoi(ps);
   if (const char* ps = std::getenv("SOL_WF_SLOTS")) s->wf_slots = std::max(4096, std::atoi(ps));
   if (const char* ps = std::getenv("SOL_WF_MIN_ITEMS")) s->wf_min_items = (uint32_t)std::max(0, std::atoi(ps));
@@ -543,8 +573,12 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
     // and keep the one with the least search work (a wide-node visit weighs ~2.5 primitive tests, by instruction count).
     // Images do not depend on the tree, the counters are deterministic, so is the choice.
     cands[0].dev = s->wides;
+    auto free_cands = [&](size_t keep) {  // candidate 0's tree belongs to the handle (s->wides)
+      for (size_t k = 1; k < cands.size(); ++k)
+        if (k != keep && cands[k].dev) { hipFree(cands[k].dev); cands[k].dev = nullptr; }
+    };
     for (size_t k = 1; k < cands.size(); ++k)
-      if ((rc = upload(cands[k].wb->out, &cands[k].dev))) return rc;
+      if ((rc = upload(cands[k].wb->out, &cands[k].dev))) { free_cands(0); return rc; }
     const uint32_t nb = s->blocks_x * s->blocks_y;
     rc = set_partition(s, 0, (int)std::max(1u, nb / 256u));
     size_t pick = 0;
@@ -559,18 +593,18 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
       for (auto& c : cands) std::fprintf(stderr, " %s %.4g (%zu nodes)", c.name.c_str(), c.cost, c.wb->out.size());
       std::fprintf(stderr, " -> %s\n", cands[pick].name.c_str());
     }
-    for (size_t k = 0; k < cands.size(); ++k)
-      if (k != pick) hipFree(cands[k].dev);
-    s->wides = cands[pick].dev;
+    if (rc) { S.wides = s->wides; free_cands(0); return rc; }
+    free_cands(pick);
+    if (pick != 0) { hipFree(s->wides); s->wides = cands[pick].dev; }
     S.wides = s->wides; S.wroot = cands[pick].wroot; s->tree_depth = cands[pick].depth;
     s->stats = SolStats{};
-    if (rc || (rc = set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
+    if ((rc = set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
   // Cost probe: per 8x8 block, the ray count of the longest 4-sample item in a counted render of the whole frame, for the
   // heavy-first work order
   // (rebuild_order; sol_path.h decode_item_ordered). SOL_ORDER=0 switches it off.
-  if (!(std::getenv("SOL_ORDER") && std::atoi(std::getenv("SOL_ORDER")) == 0) && s->blocks_x * s->blocks_y >= 64u) {
+  if (!opt.no_work_order_probe && !(std::getenv("SOL_ORDER") && std::atoi(std::getenv("SOL_ORDER")) == 0) && s->blocks_x * s->blocks_y >= 64u) {
     const uint32_t nb = s->blocks_x * s->blocks_y;
     uint32_t* cost_dev = nullptr;
     HIP_TRY(hipMalloc((void**)&cost_dev, (size_t)nb * sizeof(uint32_t)));
@@ -587,19 +621,52 @@ int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (std::getenv("SOL_VERBOSE")) std::fprintf(stderr, "[solstrale] work order: %u of %u blocks heavy (first)\n", S.n_first, s->n_local_blocks);
   }
+  s->build_times[3] = seconds_since(t_probe0);
   cleanup.keep = true;
   *out = s;
   return SOL_OK;
+}
+
+int sol_scene_build_times(const SolScene* s, double out[4]) {
+  if (!s || !out) return fail(SOL_EINVAL, "null argument");
+  for (int k = 0; k < 4; ++k) out[k] = s->build_times[k];
+  return SOL_OK;
+}
+
+int sol_scene_set_option(SolScene* s, int option, int64_t value) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  switch (option) {
+    case SOL_OPT_SWITCH_BELOW:
+      if (value < 0 || value > 64) return fail(SOL_EINVAL, "SOL_OPT_SWITCH_BELOW: 0..64");
+      s->switch_below = (uint32_t)value;
+      return SOL_OK;
+    case SOL_OPT_MAX_BLOCKS_PER_CU:
+      if (value < 0 || value > 64) return fail(SOL_EINVAL, "SOL_OPT_MAX_BLOCKS_PER_CU: 0..64");
+      s->max_bpc = (int)value;
+      return SOL_OK;
+    case SOL_OPT_KERNEL:
+      if (value < 0 || value > 3) return fail(SOL_EINVAL, "SOL_OPT_KERNEL: 0..3");
+      s->kernel_version = (int)value;
+      return SOL_OK;
+    case SOL_OPT_WORK_ORDER:
+      s->order_enabled = value != 0;
+      HIP_TRY(hipSetDevice(s->device));
+      return rebuild_order(s);
+    default: return fail(SOL_EINVAL, "unknown option %d", option);
+  }
 }
 
 int sol_scene_set_partition(SolScene* s, int rank, int world) {
   if (!s) return fail(SOL_EINVAL, "null scene");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  bool bound = s->acc != s->acc_own;
-  int rc = set_partition(s, rank, world);
-  if (rc == SOL_OK && bound) g_err = "partition changed: bound accumulator dropped";
-  return rc;
+  if (world >= 1 && s->acc != s->acc_own) {
+    const uint32_t nb = s->blocks_x * s->blocks_y;
+    const size_t floats = (size_t)((nb + (uint32_t)world - 1u) / (uint32_t)world) * 64u * 3u;
+    if (floats != s->acc_floats)
+      return fail(SOL_EINVAL, "a caller-bound accumulator of %zu floats cannot follow the new partition (%zu floats): unbind it first", s->acc_floats, floats);
+  }
+  return set_partition(s, rank, world);
 }
 
 size_t sol_accum_floats(const SolScene* s) { return s ? s->acc_floats : 0; }
@@ -640,7 +707,9 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
   P.n_local_blocks = s->n_local_blocks; P.blocks_x = s->blocks_x;
   P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
   const uint64_t items = (uint64_t)P.n_chunks * P.n_local_blocks * 64u;
-  if (items > 0xFFFF0000ull) return fail(SOL_EINVAL, "too many work items in one call (%llu): split the sample range", (unsigned long long)items);
+  // the 32-bit work counter keeps counting after the items run out (every wave adds 64 per refused fetch until all its
+  // lanes have left): 16 M of headroom is > 100 times what 5120 resident waves can add
+  if (items > SOL_MAX_ITEMS) return fail(SOL_EINVAL, "too many work items in one call (%llu): split the sample range", (unsigned long long)items);
   P.n_items = (uint32_t)items;
   if (P.n_items == 0) return SOL_OK;
   P.switch_below = s->switch_below;
@@ -650,7 +719,7 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
   // occupancy (0.45 -> 0.67-0.73) but pay for it in state traffic, refill stalls and per-round tails, so v1 is the default.
   if (version == 0) version = 1;
   int bpc = version == 3 ? sol_wf_trace_blocks_per_cu(count, s->has_medium) : sol_render_blocks_per_cu(version, count, s->has_medium);
-  if (const char* mb = std::getenv("SOL_MAX_BPC")) bpc = std::max(1, std::min(bpc, std::atoi(mb)));  // occupancy experiments
+  if (s->max_bpc > 0) bpc = std::max(1, std::min(bpc, s->max_bpc));  // SOL_OPT_MAX_BLOCKS_PER_CU
   uint32_t grid = (uint32_t)(s->n_cu * bpc);
   const uint32_t need_blocks = (P.n_items + SOL_WG - 1) / SOL_WG;
   if (grid > need_blocks) grid = need_blocks;
@@ -912,10 +981,8 @@ static int bloom_impl(SolScene* s, void* image, uint32_t spp, double ksf, double
   const double thr = threshold * (double)spp, maxi = max_intensity * (double)spp;
   const size_t k = (size_t)(ksf * (double)W) * 2 + 1;
   std::vector<double> w = gaussian_blur_weights(k, (double)k / 5.0);
-  if (!s->bloom_a) {
-    HIP_TRY(hipMalloc((void**)&s->bloom_a, n * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&s->bloom_b, n * sizeof(double)));
-  }
+  if (!s->bloom_a) HIP_TRY(hipMalloc((void**)&s->bloom_a, n * sizeof(double)));
+  if (!s->bloom_b) HIP_TRY(hipMalloc((void**)&s->bloom_b, n * sizeof(double)));
   if (k > s->bloom_w_cap) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->bloom_w) hipFree(s->bloom_w);
@@ -1008,6 +1075,175 @@ int sol_stats(const SolScene* s, SolStats* out) {
   if (!s || !out) return fail(SOL_EINVAL, "null argument");
   *out = s->stats;
   return SOL_OK;
+}
+
+}  // extern "C"
+
+// ---- multi-GPU behind the ABI: RCCL communicator + gather of the tile accumulators to rank 0 -------------------------------
+// RCCL is loaded on first use (dlopen), so that a single-GPU process has no dependency on it; when the host process has
+// already loaded an RCCL (e.g. torch's), the loader hands back that one (same soname).
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) { r.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return; }
+    auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n; return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+  });
+  return r;
+}
+#define RCCL_TRY(expr)                                                                                   \
+  do {                                                                                                   \
+    ncclResult_t r_ = (expr);                                                                            \
+    if (r_ != ncclSuccess) return fail(SOL_EDEVICE, "%s: %s", #expr, rccl().GetErrorString(r_));         \
+  } while (0)
+}  // namespace
+
+extern "C" {
+
+static_assert(sizeof(ncclUniqueId) == SOL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+int sol_comm_unique_id(uint8_t id[SOL_UNIQUE_ID_BYTES]) {
+  if (!id) return fail(SOL_EINVAL, "null argument");
+  Rccl& R = rccl();
+  if (!R.error.empty()) return fail(SOL_EDEVICE, "%s", R.error.c_str());
+  ncclUniqueId u;
+  RCCL_TRY(R.GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof u);
+  return SOL_OK;
+}
+
+int sol_comm_destroy(SolScene* s) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  if (s->comm) {
+    hipSetDevice(s->device);
+    hipStreamSynchronize(s->stream);
+    rccl().CommDestroy((ncclComm_t)s->comm);
+    s->comm = nullptr;
+  }
+  if (s->gathered) { hipFree(s->gathered); s->gathered = nullptr; s->gathered_floats = 0; }
+  return SOL_OK;
+}
+
+int sol_comm_init(SolScene* s, int rank, int world, const uint8_t id[SOL_UNIQUE_ID_BYTES]) {
+  if (!s || !id) return fail(SOL_EINVAL, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(SOL_EINVAL, "bad rank %d of %d", rank, world);
+  Rccl& R = rccl();
+  if (!R.error.empty()) return fail(SOL_EDEVICE, "%s", R.error.c_str());
+  int rc = sol_comm_destroy(s);
+  if (rc || (rc = sol_scene_set_partition(s, rank, world))) return rc;
+  HIP_TRY(hipSetDevice(s->device));
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  ncclComm_t comm = nullptr;
+  RCCL_TRY(R.CommInitRank(&comm, world, u, rank));
+  s->comm = comm;
+  return SOL_OK;
+}
+
+// One collective per emitted image: every rank's compact accumulator (equal sizes, sol_accum_floats) goes to
+// rank 0 in ONE group of point-to-point transfers - each shard rides its own xGMI link into the root - and rank 0 un-permutes
+// the `world` compact buffers into the row-major image. Without a communicator (world 1) it is sol_resolve_image into image_dev.
+int sol_gather(SolScene* s, void* image_dev) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->world > 1 && !s->comm) return fail(SOL_EINVAL, "the scene is partitioned %d-way but has no communicator: call sol_comm_init", s->world);
+  float* image = image_dev ? (float*)image_dev : s->image;
+  if (s->world == 1) {
+    HIP_TRY(sol_launch_unpermute(s->acc, image, s->S.width, s->S.height, s->blocks_x, 1u, 0u, s->acc_floats, s->stream));
+    return SOL_OK;
+  }
+  Rccl& R = rccl();
+  ncclComm_t comm = (ncclComm_t)s->comm;
+  const size_t n = s->acc_floats;
+  if (s->rank == 0) {
+    if (s->gathered_floats != n * (size_t)s->world) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      if (s->gathered) hipFree(s->gathered);
+      s->gathered = nullptr; s->gathered_floats = 0;
+      HIP_TRY(hipMalloc((void**)&s->gathered, n * (size_t)s->world * sizeof(float)));
+      s->gathered_floats = n * (size_t)s->world;
+    }
+    HIP_TRY(hipMemcpyAsync(s->gathered, s->acc, n * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    RCCL_TRY(R.GroupStart());
+    for (int r = 1; r < s->world; ++r) {
+      ncclResult_t e = R.Recv(s->gathered + (size_t)r * n, n, ncclFloat, r, comm, s->stream);
+      if (e != ncclSuccess) { R.GroupEnd(); return fail(SOL_EDEVICE, "ncclRecv from rank %d: %s", r, R.GetErrorString(e)); }
+    }
+    RCCL_TRY(R.GroupEnd());
+    HIP_TRY(sol_launch_unpermute(s->gathered, image, s->S.width, s->S.height, s->blocks_x, (uint32_t)s->world, 0xFFFFFFFFu, n, s->stream));
+  } else {
+    RCCL_TRY(R.Send(s->acc, n, ncclFloat, 0, comm, s->stream));
+  }
+  return SOL_OK;
+}
+
+// Diagnostic for boxes with ONE GPU (where no second rank can exist): moves this rank's accumulator to itself through the
+// communicator - grouped ncclSend + ncclRecv with peer = own rank, the same calls sol_gather issues - and compares the bytes.
+int sol_comm_self_check(SolScene* s) {
+  if (!s) return fail(SOL_EINVAL, "null scene");
+  if (!s->comm) return fail(SOL_EINVAL, "no communicator: call sol_comm_init");
+  HIP_TRY(hipSetDevice(s->device));
+  Rccl& R = rccl();
+  const size_t n = s->acc_floats;
+  float* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, n * sizeof(float)));
+  hipError_t e = hipMemsetAsync(tmp, 0xFF, n * sizeof(float), s->stream);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) {
+    r = R.GroupStart();
+    if (r == ncclSuccess) r = R.Send(s->acc, n, ncclFloat, s->rank, (ncclComm_t)s->comm, s->stream);
+    if (r == ncclSuccess) r = R.Recv(tmp, n, ncclFloat, s->rank, (ncclComm_t)s->comm, s->stream);
+    ncclResult_t r2 = R.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+  }
+  std::vector<float> a(n), b(n);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(a.data(), s->acc, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(b.data(), tmp, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  hipFree(tmp);
+  if (r != ncclSuccess) return fail(SOL_EDEVICE, "RCCL self transfer: %s", R.GetErrorString(r));
+  if (e != hipSuccess) return fail(SOL_EDEVICE, "self check: %s", hipGetErrorString(e));
+  if (std::memcmp(a.data(), b.data(), n * sizeof(float)) != 0) return fail(SOL_EDEVICE, "RCCL self transfer returned different bytes");
+  return SOL_OK;
+}
+
+int sol_read_image(SolScene* s, float* rgb_sum) {
+  if (!s || !rgb_sum) return fail(SOL_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(rgb_sum, s->image, (size_t)s->S.width * s->S.height * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return SOL_OK;
+}
+
+uint32_t sol_max_samples_per_call(const SolScene* s) {
+  if (!s || s->n_local_blocks == 0) return 0xFFFFFFFFu;
+  const uint64_t chunks = SOL_MAX_ITEMS / ((uint64_t)s->n_local_blocks * 64u);
+  return (uint32_t)std::min<uint64_t>(chunks * SOL_CHUNK, 0xFFFFFFF0ull);
 }
 
 }  // extern "C"

@@ -82,8 +82,10 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         const unsigned long long need = __ballot(1);
         const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
         const uint32_t n_need = (uint32_t)__popcll(need), my = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-        uint32_t* res = reservoir[tid >> 6];
-        const uint32_t next = res[0], left = res[1] - next;  // (same wave wrote them: program order)
+        // volatile: the leader's stores and every lane's loads must stay real LDS accesses in program order (one wave's LDS
+        // operations execute in order; without it the compiler may forward a stale value to the non-leader lanes)
+        volatile uint32_t* res = reservoir[tid >> 6];
+        const uint32_t next = res[0], left = res[1] - next;
         uint32_t fresh = 0;
         if (n_need > left) {  // take what is left, then continue in a fresh block of 64
           if (lane == leader) fresh = atomicAdd(work_counter, 64u);

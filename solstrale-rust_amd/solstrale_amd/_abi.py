@@ -124,6 +124,15 @@ def _sig(lib, name, res, args):
     return f
 
 
+TREE_AUTO, TREE_REF, TREE_SAH8, TREE_SAH16, TREE_SAH64, TREE_DEVICE = range(6)
+OPT_SWITCH_BELOW, OPT_MAX_BLOCKS_PER_CU, OPT_KERNEL, OPT_WORK_ORDER = 1, 2, 3, 4
+UNIQUE_ID_BYTES = 128
+
+
+class SolCreateOptions(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("world_tree", C.c_int32), ("no_work_order_probe", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
 class SolTreeCheck(C.Structure):
     _fields_ = [("n_wide", C.c_uint32), ("n_leaf_refs", C.c_uint32), ("n_primitives", C.c_uint32), ("depth", C.c_uint32),
                 ("max_children", C.c_uint32), ("box_violations", C.c_uint32), ("leaf_mismatches", C.c_uint32),
@@ -171,6 +180,16 @@ def load_hip():
     _sig(lib, "sol_kernel_timing", C.c_int, [P, C.c_int])
     _sig(lib, "sol_last_kernel_ms", C.c_int, [P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)])
     _sig(lib, "sol_eval", C.c_int, [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32])
+    _sig(lib, "sol_scene_create_ex", C.c_int, [C.POINTER(SolSceneDesc), C.c_int, C.POINTER(SolCreateOptions), C.POINTER(P)])
+    _sig(lib, "sol_scene_build_times", C.c_int, [P, C.POINTER(C.c_double)])
+    _sig(lib, "sol_scene_set_option", C.c_int, [P, C.c_int, C.c_int64])
+    _sig(lib, "sol_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)])
+    _sig(lib, "sol_comm_init", C.c_int, [P, C.c_int, C.c_int, C.POINTER(C.c_uint8)])
+    _sig(lib, "sol_comm_destroy", C.c_int, [P])
+    _sig(lib, "sol_gather", C.c_int, [P, C.c_void_p])
+    _sig(lib, "sol_comm_self_check", C.c_int, [P])
+    _sig(lib, "sol_read_image", C.c_int, [P, C.POINTER(C.c_float)])
+    _sig(lib, "sol_max_samples_per_call", C.c_uint32, [P])
     _libs["hip"] = lib
     return lib
 
@@ -179,7 +198,9 @@ HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol
                "sol_accum_floats", "sol_accum_ptr", "sol_scene_bind_accum", "sol_scene_set_stream", "sol_clear",
                "sol_render", "sol_render_counted", "sol_sync", "sol_read", "sol_unpermute", "sol_tonemap_rgb8",
                "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms",
-               "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check", "sol_render_aux", "sol_clear_aux", "sol_read_aux"]
+               "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check", "sol_render_aux", "sol_clear_aux", "sol_read_aux",
+               "sol_scene_create_ex", "sol_scene_build_times", "sol_scene_set_option", "sol_comm_unique_id", "sol_comm_init",
+               "sol_comm_destroy", "sol_gather", "sol_comm_self_check", "sol_read_image", "sol_max_samples_per_call"]
 
 
 def load_host():

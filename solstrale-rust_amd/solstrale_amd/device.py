@@ -18,6 +18,16 @@ def device_count():
     return int(_abi.load_hip().sol_device_count())
 
 
+def comm_unique_id():
+    """sol_comm_unique_id: 128 bytes rank 0 ships to the other ranks before sol_comm_init."""
+    lib = _abi.load_hip()
+    buf = (C.c_uint8 * _abi.UNIQUE_ID_BYTES)()
+    rc = lib.sol_comm_unique_id(buf)
+    if rc != 0:
+        raise DeviceError(rc, lib.sol_last_error().decode())
+    return bytes(buf)
+
+
 def record_sizes():
     out = (C.c_uint32 * 6)()
     _abi.load_hip().sol_record_sizes(out)
@@ -48,11 +58,16 @@ def world_tree_check(scene, use_sah):
 class DeviceScene:
     """sol_scene_create .. sol_scene_destroy"""
 
-    def __init__(self, scene, device=0):
+    def __init__(self, scene, device=0, world_tree=None, no_work_order_probe=False):
         self.lib = _abi.load_hip()
         self.scene = scene
         self.h = C.c_void_p()
-        rc = self.lib.sol_scene_create(scene.desc_ptr, device, C.byref(self.h))
+        if world_tree is None and not no_work_order_probe:
+            rc = self.lib.sol_scene_create(scene.desc_ptr, device, C.byref(self.h))
+        else:
+            opt = _abi.SolCreateOptions(size=C.sizeof(_abi.SolCreateOptions), world_tree=int(world_tree or 0),
+                                        no_work_order_probe=1 if no_work_order_probe else 0)
+            rc = self.lib.sol_scene_create_ex(scene.desc_ptr, device, C.byref(opt), C.byref(self.h))
         if rc != 0:
             self.h = None
             raise DeviceError(rc, self.lib.sol_last_error().decode())
@@ -81,6 +96,38 @@ class DeviceScene:
 
     def set_partition(self, rank, world):
         self._chk(self.lib.sol_scene_set_partition(self.h, rank, world))
+
+    def set_option(self, option, value):
+        self._chk(self.lib.sol_scene_set_option(self.h, int(option), int(value)))
+
+    def build_times(self):
+        """Seconds sol_scene_create spent in host tree candidates / uploads / device tree build / probe renders."""
+        out = (C.c_double * 4)()
+        self._chk(self.lib.sol_scene_build_times(self.h, out))
+        return dict(zip(("host_trees", "upload", "device_tree", "probes"), [float(x) for x in out]))
+
+    def max_samples_per_call(self):
+        return int(self.lib.sol_max_samples_per_call(self.h))
+
+    def comm_init(self, rank, world, unique_id):
+        """sol_comm_init: RCCL communicator of the tile partition (collective over the ranks); also sets the partition."""
+        buf = (C.c_uint8 * _abi.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._chk(self.lib.sol_comm_init(self.h, rank, world, buf))
+
+    def comm_destroy(self):
+        self._chk(self.lib.sol_comm_destroy(self.h))
+
+    def gather(self, image_ptr=0):
+        """sol_gather: collective; rank 0 gets the row-major image in device memory `image_ptr` (0: the scene's own buffer)."""
+        self._chk(self.lib.sol_gather(self.h, C.c_void_p(image_ptr)))
+
+    def comm_self_check(self):
+        self._chk(self.lib.sol_comm_self_check(self.h))
+
+    def read_image(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._chk(self.lib.sol_read_image(self.h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def set_stream(self, hip_stream):
         self._chk(self.lib.sol_scene_set_stream(self.h, C.c_void_p(hip_stream)))

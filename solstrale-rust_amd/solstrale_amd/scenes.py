@@ -224,6 +224,56 @@ def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1
     return b.finish(world, cam, (0.35, 0.5, 0.75), rc)
 
 
+def obj_bounds(path):
+    """Axis-aligned bounds of the `v` lines of an OBJ file (for placing a default camera and light)."""
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            if line.startswith("v "):
+                p = line.split()
+                if len(p) >= 4:
+                    v = np.array([float(p[1]), float(p[2]), float(p[3])])
+                    lo, hi = np.minimum(lo, v), np.maximum(hi, v)
+    if not np.isfinite(lo).all():
+        raise ValueError(f"{path}: no vertices")
+    return lo, hi
+
+
+def obj_file_scene(path, render_config=None, camera=None, light=None, background=(0.35, 0.5, 0.75)):
+    """A user-supplied OBJ (+MTL, textures beside it) in place of a stand-in, e.g. the real Crytek sponza.obj for C3
+    ("if a real sponza.obj is supplied at run time, use it and say so"). Loaded by the C++ host's OBJ loader
+    with the reference's material mapping (src/loader/obj.rs:38-136). camera = (look_from, look_at, vfov) and
+    light = (q, u, v, rgb) override the defaults: an eye at 15 % of the long horizontal axis, 30 % up, looking down that axis,
+    and a Quad light over the middle third of the model's top (y up), as in the atrium stand-in."""
+    rc = render_config or RenderConfig(width=1920, height=1080, samples_per_pixel=512)
+    d, fn = os.path.split(os.path.abspath(path))
+    lo, hi = obj_bounds(path)
+    ext = hi - lo
+    ax = 0 if ext[0] >= ext[2] else 2  # long horizontal axis
+    ox = 2 - ax
+    b = SceneBuilder()
+    model = b.load_obj(d + os.sep, fn, None, b.Lambertian(b.SolidColor(0.7, 0.7, 0.7)))
+    if light is None:
+        q = lo.copy()
+        q[1] = hi[1] + 0.02 * ext[1]
+        q[ax] = lo[ax] + ext[ax] / 3.0
+        q[ox] = lo[ox] + ext[ox] / 3.0
+        u, v = np.zeros(3), np.zeros(3)
+        u[ax], v[ox] = ext[ax] / 3.0, ext[ox] / 3.0
+        light = (q, u, v, (18., 17., 15.))
+    lq = b.Quad(tuple(light[0]), tuple(light[1]), tuple(light[2]), b.DiffuseLight(*light[3]))
+    if camera is None:
+        eye, at = lo + 0.5 * ext, lo + 0.5 * ext
+        eye[ax] = lo[ax] + 0.15 * ext[ax]
+        eye[1] = lo[1] + 0.3 * ext[1]
+        at[ax] = lo[ax] + 0.8 * ext[ax]
+        at[1] = lo[1] + 0.4 * ext[1]
+        camera = (eye, at, 55.)
+    cam = CameraConfig(vertical_fov_degrees=float(camera[2]), aperture_size=0., look_from=tuple(camera[0]), look_at=tuple(camera[1]),
+                       up=(0, 1, 0))
+    return b.finish(b.Bvh([model, lq]), cam, background, rc)
+
+
 STATUE_TRIANGLES = 1_090_000
 
 

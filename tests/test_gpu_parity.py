@@ -415,6 +415,77 @@ def test_full_size_c2_properties():
     assert pu.compare(whole, ref, 256, rect=(960, 540, 992, 572))["bad_pixels"] == 0
 
 
+def test_full_size_c3_properties():
+    """configs[2] at its full size (262 267 triangles, 1920x1080, 512 spp - the headline): additivity over sample ranges (row flip
+    and sums as src/renderer/mod.rs:261-268,361-365), tile ownership of an 8-way partition, and a 512-spp oracle crop."""
+    sc = scenes.sponza_like(RenderConfig(1920, 1080, 512))
+    with DeviceScene(sc) as ds:
+        ds.render(0, 512, pu.SEED)
+        whole = ds.read()
+        ds.clear()
+        for f in range(0, 512, 128):
+            ds.render(f, 128, pu.SEED)
+        parts = ds.read()
+        ds.clear()
+        ds.set_partition(3, 8)
+        ds.render(0, 512, pu.SEED)
+        r3 = ds.read()
+    assert np.isfinite(whole).all() and (whole >= 0).all()
+    assert (whole == parts).all()
+    from solstrale_amd import tiles
+    owner, _ = tiles._slots(1920, 1080, 8)
+    owned = owner == 3
+    assert 0.12 < owned.mean() < 0.13 and (r3[owned] == whole[owned]).all() and not r3[~owned].any()
+    rect = (1000, 600, 1024, 624)
+    ref, _ = orc.render(sc, 0, 512, pu.SEED, real=orc.ORC_F32, rect=rect)
+    res = pu.compare(whole, ref, 512, rect=rect)
+    assert res["bad_pixels"] == 0 and res["max_rel"] <= pu.REL_TOL, res
+
+
+def test_c4_4k_crop_and_properties():
+    """configs[3]: the Sponza-class scene at 3840x2160 x 1024 spp, tiles over 8 GPUs. On one GPU: two 128x128 oracle crops of the
+    4K frame, additivity, and ONE RANK'S SHARE of the real job - rank 3 of 8 renders its tiles with all 1024 spp (64 chunks: the
+    6.4 GB-class partial plane at 1/8 scale, blocks_x = 480, item counts near the 32-bit work counter's range when un-split)
+    - checked against the sum of four 256-spp ranges and against a 1024-spp oracle crop on the pixels rank 3 owns."""
+    sc = scenes.sponza_like(RenderConfig(3840, 2160, 1024))
+    assert sc.desc.n_triangles == scenes.SPONZA_TRIANGLES
+    from solstrale_amd import tiles
+    owner, _ = tiles._slots(3840, 2160, 8)
+    owned = owner == 3
+    with DeviceScene(sc) as ds:
+        assert ds.max_samples_per_call() >= 1024 // 8  # the whole frame needs split calls at 1024 spp; a rank's share does not
+        ds.render(0, 16, pu.SEED)
+        img16 = ds.read()
+        ds.clear()
+        ds.render(0, 4, pu.SEED)
+        ds.render(4, 12, pu.SEED)  # not chunk aligned: the second call starts inside chunk 0
+        img_split = ds.read()
+        ds.clear()
+        ds.set_partition(3, 8)
+        ds.render(0, 1024, pu.SEED)
+        r3 = ds.read()
+        ds.clear()
+        for f in range(0, 1024, 256):
+            ds.render(f, 256, pu.SEED)
+        r3_parts = ds.read()
+    assert np.isfinite(img16).all() and (img16 >= 0).all() and np.isfinite(r3).all()
+    for rect, spp in (((1800, 1000, 1928, 1128), 16), ((0, 2032, 128, 2160), 16)):
+        ref, _ = orc.render(sc, 0, spp, pu.SEED, real=orc.ORC_F32, rect=rect)
+        res = pu.compare(img16, ref, spp, rect=rect)
+        assert res["bad_pixels"] == 0 and res["max_rel"] <= pu.REL_TOL, (rect, res)
+    # sample ranges split off the chunk grid change the summation order (4 + 12 vs 16 in one chunk): equal within rounding
+    assert np.allclose(img_split, img16, rtol=2e-6, atol=1e-6)
+    assert (r3 == r3_parts).all() and not r3[~owned].any() and 0.12 < owned.mean() < 0.13
+    rect = (2000, 1200, 2016, 1216)
+    ref, _ = orc.render(sc, 0, 1024, pu.SEED, real=orc.ORC_F32, rect=rect)
+    y, x = np.mgrid[rect[1]:rect[3], rect[0]:rect[2]]
+    m = owned[y, x]
+    assert m.any()
+    g = r3[rect[1]:rect[3], rect[0]:rect[2]][m].astype(np.float64)
+    r = ref[rect[1]:rect[3], rect[0]:rect[2]][m].astype(np.float64)
+    assert (np.abs(g - r) <= pu.REL_TOL * np.abs(r) + pu.REL_TOL * 1024 * 1e-2).all()
+
+
 def test_aux_albedo_and_normal_buffers():
     """renderer/mod.rs:175-204: at depth 0 the albedo shader's and the normal shader's colours of the primary hit are accumulated
     beside the pixel colour (background / zero on a miss). They equal the single-hit shaders' renders of the same samples."""

@@ -24,10 +24,19 @@ def main():
             if row["Dispatch_Id"] not in seen:
                 seen.add(row["Dispatch_Id"])
                 dur_ns.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
-    c = counters
+    c = c0 = counters
     g = lambda k: c.get(k, float("nan"))
     n_simd = 256 * 4
     kernel_ms = sum(dur_ns) / max(1, len(dur_ns)) / 1e6
+    # shader clock during the profiled launch: GRBM_GUI_ACTIVE sums the 8 XCDs (guide, "DVFS give-back"); else SQ_BUSY_CYCLES
+    # (summed over the 32 shader engines); else the 2.4 GHz maximum
+    if "GRBM_GUI_ACTIVE" in c0:
+        clock = c0["GRBM_GUI_ACTIVE"] / 8.0 / (kernel_ms * 1e-3)
+    elif "SQ_BUSY_CYCLES" in c0:
+        clock = c0["SQ_BUSY_CYCLES"] / 32.0 / (kernel_ms * 1e-3)
+    else:
+        clock = 2.4e9
+    k_cycles = kernel_ms * 1e-3 * clock
     d = {
         "kernel_ms_under_pmc (mean of the passes)": round(kernel_ms, 2),
         "valu_insts_per_sample": g("SQ_INSTS_VALU") / samples,
@@ -36,18 +45,23 @@ def main():
         "lds_insts_per_sample": g("SQ_INSTS_LDS") / samples,
         # SQ_* cycle counters count quad-cycles (guide: 'tick vs SQ PMC units')
         "valu_lane_utilization (THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64))": g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64.0),
-        "simd_valu_busy_frac (ACTIVE_INST_VALU*4 / (SIMDs * kernel cycles @2.4GHz))": g("SQ_ACTIVE_INST_VALU") * 4.0 / (n_simd * kernel_ms * 1e-3 * 2.4e9),
+        "shader_clock_ghz": clock / 1e9,
+        "simd_valu_busy_frac_at_4_cycles_per_instr (ACTIVE_INST_VALU*4 / (SIMDs * kernel cycles))": g("SQ_ACTIVE_INST_VALU") * 4.0 / (n_simd * k_cycles),
+        "valu_issue_frac_of_2_cycle_peak (INSTS_VALU*2 / (SIMDs * kernel cycles))": g("SQ_INSTS_VALU") * 2.0 / (n_simd * k_cycles),
         "wave_cycles_waiting_frac (WAIT_ANY / WAVE_CYCLES)": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"),
         "wave_cycles_issue_stall_frac (WAIT_INST_ANY / WAVE_CYCLES)": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
-        "mean_waves_per_simd (WAVE_CYCLES / BUSY_CYCLES ... per SE-normalised)": g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CYCLES"),
+        "mean_waves_per_simd (WAVE_CYCLES*4 / (SIMDs * kernel cycles))": g("SQ_WAVE_CYCLES") * 4.0 / (n_simd * k_cycles),
         "l1_hit_rate (1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)": 1.0 - g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum"),
         "l2_hit_rate (TCC_HIT / (TCC_HIT + TCC_MISS))": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")),
-        "ta_busy_percent_avr": g("TA_BUSY_avr"),
+        "ta_busy_frac (TA_BUSY_avr cycles / kernel cycles)": g("TA_BUSY_avr") / k_cycles,
+        "td_busy_frac (TD_TD_BUSY_sum / (256 CUs * kernel cycles))": g("TD_TD_BUSY_sum") / (256.0 * k_cycles),
         "fabric_read_bytes_uncorrected (FETCH_SIZE KiB * 1024)": g("FETCH_SIZE") * 1024.0,
         "fabric_read_bytes_corrected_x2": g("FETCH_SIZE") * 2048.0,
         "fabric_write_bytes (WRITE_SIZE KiB * 1024)": g("WRITE_SIZE") * 1024.0,
         "fabric_bytes_per_sample_corrected": (g("FETCH_SIZE") * 2048.0 + g("WRITE_SIZE") * 1024.0) / samples,
     }
+    d = {k: v for k, v in d.items() if v == v}  # drop rows whose counters were not collected (NaN)
+    counters = {k: v for k, v in counters.items() if not (k == "SQ_ACTIVE_INST_VMEM" and v == 0.0)}  # reads 0 on gfx950: not a measurement
     json.dump({"kernel": kname, "samples_in_launch": samples, "counters": counters, "derived": d}, sys.stdout, indent=1)
     print()
 
