@@ -61,12 +61,29 @@ int upload(const std::vector<T>& host, T** dev) {
 
 #define SOL_MAX_ITEMS 0xFF000000ull
 
+// Device memory that depends on the choice of the world tree (sol_scene_create probes several candidates): the 7-wide tree, the
+// primitive arrays in that tree's leaf order and every table holding references into them.
+struct DevTree {
+  DWide* wides = nullptr; uint32_t* leaf_refs = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
+  DSphere* spheres = nullptr; DNode* nodes = nullptr; DMedium* mediums = nullptr; uint32_t* lights = nullptr;
+  uint32_t emin = 1, depth = 0, root = 0;
+  std::vector<uint32_t> old_tri, old_sphere, old_quad;  // device index -> index in the caller's arrays
+  void release() {
+    void* p[] = {wides, leaf_refs, tris, tri_shade, quads, spheres, nodes, mediums, lights};
+    for (void* q : p) if (q) hipFree(q);
+    *this = DevTree{};
+  }
+};
+
 struct SolScene {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevScene S{};
   DevScene* dscene = nullptr; DevScene S_uploaded{}; bool dscene_valid = false;  // device copy of S (the v1 kernel reads it through a pointer)
   // owned device buffers
+  std::vector<uint32_t> old_index[3];  // triangles / spheres / quads: device index -> index in the caller's SolSceneDesc arrays
+  std::string tree_name;               // which world tree the handle walks ("ref", "sah8", .., "device")
+  uint32_t* leaf_refs = nullptr;
   DNode* nodes = nullptr; DWide* wides = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
   DSphere* spheres = nullptr; DMedium* mediums = nullptr; DMat* mats = nullptr; DTex* texs = nullptr;
   uint8_t* texels = nullptr; uint32_t* lights = nullptr;
@@ -189,38 +206,54 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
   if (use_sah) { Box b; sah.BINS = use_sah > 1 ? std::min((int)SahBuilder::MAX_BINS, use_sah) : 16; bin_root = sah.build(0, sah.prims.size(), 0, b); }
   WideBuilder wb(use_sah ? sah.nodes : tb.nodes, box_pad);
   wb.dp_collapse = !(std::getenv("SOL_COLLAPSE") && std::strcmp(std::getenv("SOL_COLLAPSE"), "greedy") == 0);
-  const uint32_t wroot = wb.build(SOL_REF_INDEX(bin_root), 0);
-  out->n_wide = (uint32_t)wb.out.size();
-  out->depth = wb.max_depth;
+  wb.set_exponent_range(root_box);
+  const uint32_t xroot = wb.build(SOL_REF_INDEX(bin_root), 0);
+  WideLayout lay;
+  if (wb.range_error || !lay.run(wb.out, SOL_REF_INDEX(xroot), wb.emin, d->n_triangles, d->n_spheres, d->n_quads))
+    return fail(SOL_EINVAL, "wide tree layout: %s", wb.range_error ? "exponent range" : lay.error.c_str());
+  out->n_wide = (uint32_t)lay.nodes.size();
+  out->depth = lay.depth;
   out->inner_area = wb.inner_area; out->leaf_area = wb.leaf_area;
   std::map<uint32_t, int> found;
-  // returns the union of the padded primitive boxes below `ref`
-  std::function<Box(uint32_t, uint32_t)> walk = [&](uint32_t ref, uint32_t depth) -> Box {
-    if (SOL_REF_KIND(ref) != SOL_REF_WIDE) {
-      found[ref]++;
-      out->n_leaf_refs++;
-      auto it = prim_box.find(ref);
-      return it == prim_box.end() ? empty_box() : it->second;
-    }
+  // The DEVICE form is what gets checked, decoded exactly as the kernel decodes it (sol_trace.h): 5-bit exponents over emin,
+  // implicit child addresses, permuted primitive arrays (mapped back to the caller's indices for the comparison).
+  const uint32_t ref_kind_of[4] = {SOL_REF_NONE, SOL_REF_TRIANGLE, SOL_REF_SPHERE, SOL_REF_QUAD};
+  // returns the union of the padded primitive boxes below node `ni`
+  std::function<Box(uint32_t, uint32_t)> walk = [&](uint32_t ni, uint32_t depth) -> Box {
     Box all = empty_box();
-    if (depth > 4096 || SOL_REF_INDEX(ref) >= wb.out.size()) { out->leaf_mismatches++; return all; }
-    const DWide& w = wb.out[SOL_REF_INDEX(ref)];
+    if (depth > 4096 || ni >= lay.nodes.size()) { out->leaf_mismatches++; return all; }
+    const DWide& w = lay.nodes[ni];
     const float origin[3] = {w.ox, w.oy, w.oz};
     float scale[3];
-    for (int a = 0; a < 3; ++a) { uint32_t bits = ((w.meta >> (8 * a)) & 0xFFu) << 23; std::memcpy(&scale[a], &bits, 4); }
+    for (int a = 0; a < 3; ++a) { uint32_t bits = (((w.meta >> (5 * a)) & 31u) + wb.emin) << 23; std::memcpy(&scale[a], &bits, 4); }
+    const uint32_t imask = (w.meta >> 15) & 0x7Fu, lmask = (w.meta >> 22) & 0x7Fu, kind = (w.meta >> 29) & 3u;
+    if (imask & lmask) out->bad_empty_slots++;
     uint32_t n_children = 0;
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < SOL_WIDE_CHILDREN; ++s) {
       uint32_t ql[3], qh[3];
       for (int a = 0; a < 3; ++a) {
         ql[a] = (w.q[2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xFFu;
         qh[a] = (w.q[6 + 2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xFFu;
       }
-      if (SOL_REF_KIND(w.ref[s]) == SOL_REF_NONE) {
+      const uint32_t bit = 1u << s, below_mask = bit - 1u;
+      if (!((imask | lmask) & bit)) {  // an empty slot must have an inverted box (never hit)
         if (!(ql[0] == 255u && qh[0] == 0u && ql[1] == 255u && qh[1] == 0u && ql[2] == 255u && qh[2] == 0u)) out->bad_empty_slots++;
         continue;
       }
       n_children++;
-      const Box below = walk(w.ref[s], depth + 1);
+      Box below;
+      if (imask & bit) {
+        below = walk(WideLayout::base_inner(w) + (uint32_t)__builtin_popcount(imask & below_mask), depth + 1);
+      } else {
+        const uint32_t idx = WideLayout::base_prim(w) + (uint32_t)__builtin_popcount(lmask & below_mask);
+        uint32_t ref = kind == SOL_LEAF_REFS ? (idx < lay.leaf_refs.size() ? lay.leaf_refs[idx] : 0u) : SOL_MAKE_REF(ref_kind_of[kind], idx);
+        const int a = WideLayout::arr(SOL_REF_KIND(ref));
+        if (a >= 0) ref = SOL_REF_INDEX(ref) < lay.old_of_new[a].size() ? SOL_MAKE_REF(SOL_REF_KIND(ref), lay.old_of_new[a][SOL_REF_INDEX(ref)]) : 0u;
+        found[ref]++;
+        out->n_leaf_refs++;
+        auto it = prim_box.find(ref);
+        below = it == prim_box.end() ? empty_box() : it->second;
+      }
       bool ok = true;
       for (int a = 0; a < 3; ++a) {
         const float lo = WideBuilder::decode(origin[a], ql[a], scale[a]), hi = WideBuilder::decode(origin[a], qh[a], scale[a]);
@@ -232,7 +265,13 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
     if (n_children > out->max_children) out->max_children = n_children;
     return all;
   };
-  walk(wroot, 0);
+  walk(0, 0);
+  // the permutations must be permutations
+  for (int a = 0; a < 3; ++a) {
+    std::vector<uint8_t> seen(lay.old_of_new[a].size(), 0);
+    for (uint32_t o : lay.old_of_new[a]) { if (o >= seen.size() || seen[o]) out->leaf_mismatches++; else seen[o] = 1; }
+    if (lay.old_of_new[a].size() != lay.new_of_old[a].size()) out->leaf_mismatches++;
+  }
   for (const auto& e : expected) {
     auto it = found.find(e.first);
     const int f = it == found.end() ? 0 : it->second;
@@ -254,7 +293,7 @@ void sol_scene_destroy(SolScene* s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   sol_comm_destroy(s);
-  void* ptrs[] = {s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
+  void* ptrs[] = {s->leaf_refs, s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
                   s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters, s->pool, s->queue, s->wf_ctr,
                   s->bloom_a, s->bloom_b, s->bloom_w, s->aux[0], s->aux[1], s->dscene, s->order_dev};
   if (s->wf_ctr_host) hipHostFree(s->wf_ctr_host);
@@ -352,9 +391,9 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     o.v0x = (float)t.v0[0]; o.v0y = (float)t.v0[1]; o.v0z = (float)t.v0[2];
     o.e1x = (float)t.v0v1[0]; o.e1y = (float)t.v0v1[1]; o.e1z = (float)t.v0v1[2];
     o.e2x = (float)t.v0v2[0]; o.e2y = (float)t.v0v2[1]; o.e2z = (float)t.v0v2[2];
-    o.dfs = t.dfs_index; o.mat = t.material; o.pad = 0;
+    o.dfs = t.dfs_index; o.mat = t.material; o.area = (float)t.area;
     DTriShade& s = tshade[i];
-    s.nx = (float)t.normal[0]; s.ny = (float)t.normal[1]; s.nz = (float)t.normal[2]; s.area = (float)t.area;
+    s.nx = (float)t.normal[0]; s.ny = (float)t.normal[1]; s.nz = (float)t.normal[2]; s.mat = t.material;
     s.tx = (float)t.tangent[0]; s.ty = (float)t.tangent[1]; s.tz = (float)t.tangent[2];
     s.bx = (float)t.bi_tangent[0]; s.by = (float)t.bi_tangent[1]; s.bz = (float)t.bi_tangent[2];
     s.u0 = t.uv0[0]; s.v0 = t.uv0[1]; s.u1 = t.uv1[0]; s.v1 = t.uv1[1]; s.u2 = t.uv2[0]; s.v2 = t.uv2[1];
@@ -413,35 +452,46 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
       if (SOL_REF_KIND(r) == SOL_REF_NODE) { stk.push_back(tb.nodes[SOL_REF_INDEX(r)].left); stk.push_back(tb.nodes[SOL_REF_INDEX(r)].right); }
     }
   }
-  // 8-wide tree of the world (a visit may push up to 7 children). Candidates: the reference's topology collapsed, and
-  // binned-SAH rebuilds over the same primitives with 8, 16 and 64 bins (how well the binary splits line up with the 8-wide
-  // collapse varies with the bin count: C2 visits 9.8 / 12.2 / 11.4 nodes per ray at 8 / 16 / 64 bins, 11.2 on the
-  // reference's topology; C3 13.3 / 13.0 / 12.9 vs 14.4). A counted probe render on the device picks one (below).
-  // SOL_BVH=ref | sah (16 bins) | sah8 | sah16 | sah64 forces a candidate (A/B runs, deep-tree tests).
+  // 7-wide tree of the world. Candidates: the reference's topology collapsed, and binned-SAH rebuilds over the same primitives
+  // with 8, 16 and 64 bins (how well the binary splits line up with the wide collapse varies with the bin count: with the
+  // first, 8-wide layout C2 visited 9.8 / 12.2 / 11.4 nodes per ray at 8 / 16 / 64 bins and 11.2 on the reference's
+  // topology; C3 13.3 / 13.0 / 12.9 vs 14.4). A counted probe render on the device picks one (below).
+  // SolCreateOptions.world_tree (or SOL_BVH=ref | sah (16 bins) | sah8 | sah16 | sah64) forces a candidate.
   struct TreeCand {
     std::string name;
     std::unique_ptr<SahBuilder> sah;
     std::unique_ptr<WideBuilder> wb;
-    uint32_t wroot = 0, depth = 0;
-    DWide* dev = nullptr;
+    WideLayout lay;
+    uint32_t depth = 0;
+    DevTree dev;
     double cost = 0.;
   };
   std::vector<TreeCand> cands;
-  auto depth_of = [&](const WideBuilder& w) { return (SOL_WORLD_BINARY ? world_depth : 7u * w.max_depth) + medium_depth + 2; };
+  // stack entries (dwords): a wide level keeps at most one sibling group of two dwords
+  auto depth_of = [&](const WideLayout& l) { return (SOL_WORLD_BINARY ? world_depth : 2u * l.depth) + medium_depth + 2; };
   const uint32_t stack_limit = SOL_LDS_STACK + SOL_SPILL_STACK;
   const char* bvh_env = std::getenv("SOL_BVH");  // developer override of SolCreateOptions.world_tree
   static const char* const tree_names[] = {"", "ref", "sah8", "sah16", "sah64", "device"};
   const std::string want = bvh_env ? (std::strcmp(bvh_env, "sah") == 0 ? "sah16" : bvh_env) : tree_names[opt.world_tree];
-  uint32_t wroot = root_ref;
+  const bool greedy = std::getenv("SOL_COLLAPSE") && std::strcmp(std::getenv("SOL_COLLAPSE"), "greedy") == 0;
+  auto finish_cand = [&](TreeCand& c, uint32_t wide_root) {  // explicit tree -> device layout
+    if (c.wb->range_error || !c.lay.run(c.wb->out, SOL_REF_INDEX(wide_root), c.wb->emin, d->n_triangles, d->n_spheres, d->n_quads)) {
+      c.wb.reset();
+      return;
+    }
+    c.depth = depth_of(c.lay);
+  };
+  std::string layout_error;
   if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) {
     {
       TreeCand c;
       c.name = "ref";
       c.wb.reset(new WideBuilder(tb.nodes, box_pad));
-      c.wb->dp_collapse = !(std::getenv("SOL_COLLAPSE") && std::strcmp(std::getenv("SOL_COLLAPSE"), "greedy") == 0);
-      c.wroot = c.wb->build(SOL_REF_INDEX(root_ref), 0);
-      c.depth = depth_of(*c.wb);
-      cands.push_back(std::move(c));
+      c.wb->dp_collapse = !greedy;
+      c.wb->set_exponent_range(root_box);
+      finish_cand(c, c.wb->build(SOL_REF_INDEX(root_ref), 0));
+      if (!c.wb) layout_error = c.lay.error.empty() ? "wide tree: exponent range" : c.lay.error;
+      else cands.push_back(std::move(c));
     }
     std::vector<int> bin_list = {8, 16, 64};
     if (const char* bl = std::getenv("SOL_SAH_LIST")) {  // experiment: other candidate sets, e.g. SOL_SAH_LIST=4,12,32
@@ -462,9 +512,9 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
         Box bx;
         const uint32_t r = c.sah->build(0, c.sah->prims.size(), 0, bx);
         c.wb.reset(new WideBuilder(c.sah->nodes, box_pad));
-        c.wb->dp_collapse = !(std::getenv("SOL_COLLAPSE") && std::strcmp(std::getenv("SOL_COLLAPSE"), "greedy") == 0);
-        c.wroot = c.wb->build(SOL_REF_INDEX(r), 0);
-        c.depth = depth_of(*c.wb);
+        c.wb->dp_collapse = !greedy;
+        c.wb->set_exponent_range(root_box);
+        finish_cand(c, c.wb->build(SOL_REF_INDEX(r), 0));
         return c;
       }));
     }
@@ -472,13 +522,14 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
       TreeCand c = j.get();
       if (c.wb) cands.push_back(std::move(c));
     }
+    if (cands.empty()) return fail(SOL_EINVAL, "world: %s", layout_error.c_str());
     // drop what cannot run; a forced choice drops the rest
     std::vector<TreeCand> keep;
     for (auto& c : cands)
       if (c.depth <= stack_limit && (want.empty() || c.name == want || (want != "ref" && c.name == "ref" && cands.size() == 1))) keep.push_back(std::move(c));
     if (keep.empty()) {
       uint32_t dmin = 0xFFFFFFFFu;
-      for (auto& c : cands) dmin = std::min(dmin, c.depth);
+      for (auto& c : cands) if (c.wb) dmin = std::min(dmin, c.depth);
       return fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", dmin, stack_limit);
     }
     cands = std::move(keep);
@@ -487,12 +538,16 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     for (size_t i = 1; i < cands.size(); ++i)
       if (cands[i].wb->cost() < cands[best].wb->cost()) best = i;
     std::swap(cands[0], cands[best]);
-    wroot = cands[0].wroot;
+  } else {  // the world is ONE primitive: a root with a single child
+    TreeCand c;
+    c.name = "ref";
+    c.wb.reset(new WideBuilder(tb.nodes, box_pad));
+    c.wb->set_exponent_range(root_box);
+    finish_cand(c, c.wb->build_single(root_ref, root_box));
+    if (!c.wb) return fail(SOL_EINVAL, "world: %s", c.lay.error.c_str());
+    cands.push_back(std::move(c));
   }
   const bool calibrate = cands.size() > 1 && !SOL_WORLD_BINARY;
-  static const std::vector<DWide> no_wides;
-  const std::vector<DWide>& wides0 = cands.empty() ? no_wides : cands[0].wb->out;
-  uint32_t tree_depth = cands.empty() ? medium_depth + 2 : cands[0].depth;
 
   const double t_host_trees = seconds_since(t_begin);
 
@@ -520,12 +575,54 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   s->stream = s->own_stream;
   int rc;
-  if ((rc = upload(tb.nodes, &s->nodes)) || (rc = upload(wides0, &s->wides)) || (rc = upload(tris, &s->tris)) || (rc = upload(tshade, &s->tri_shade)) ||
-      (rc = upload(quads, &s->quads)) || (rc = upload(spheres, &s->spheres)) || (rc = upload(mediums, &s->mediums)) ||
-      (rc = upload(mats, &s->mats)) || (rc = upload(texs, &s->texs)) || (rc = upload(lights, &s->lights)))
-    return rc;
-  std::vector<uint8_t> texels(d->texels, d->texels + d->n_texel_bytes);
-  if ((rc = upload(texels, &s->texels))) return rc;
+  // everything that depends on the choice of the world tree: the tree itself, the permuted primitive arrays and every table of
+  // references into them (DevTree); candidate 0 first, the others only if a probe has to decide
+  const bool need_binary = SOL_WORLD_BINARY || d->n_mediums > 0;  // the 2-wide tree serves medium boundaries (and the A/B build) only
+  auto upload_tree = [&](TreeCand& c) -> int {
+    const WideLayout& L = c.lay;
+    DevTree& t = c.dev;
+    std::vector<DTri> ptris(tris.size());
+    std::vector<DTriShade> pshade(tshade.size());
+    std::vector<DQuad> pquads(quads.size());
+    std::vector<DSphere> pspheres(spheres.size());
+    for (size_t i = 0; i < tris.size(); ++i) { ptris[i] = tris[L.old_of_new[0][i]]; pshade[i] = tshade[L.old_of_new[0][i]]; }
+    for (size_t i = 0; i < spheres.size(); ++i) pspheres[i] = spheres[L.old_of_new[1][i]];
+    for (size_t i = 0; i < quads.size(); ++i) pquads[i] = quads[L.old_of_new[2][i]];
+    std::vector<DNode> pnodes;
+    if (need_binary) {
+      pnodes = tb.nodes;
+      for (auto& n : pnodes) { n.left = L.remap(n.left); n.right = L.remap(n.right); }
+    }
+    std::vector<DMedium> pmed = mediums;
+    for (auto& m : pmed) m.boundary = L.remap(m.boundary);
+    std::vector<uint32_t> plights = lights;
+    for (auto& r : plights) r = L.remap(r);
+    int e;
+    if ((e = upload(L.nodes, &t.wides)) || (e = upload(L.leaf_refs, &t.leaf_refs)) || (e = upload(ptris, &t.tris)) || (e = upload(pshade, &t.tri_shade)) ||
+        (e = upload(pquads, &t.quads)) || (e = upload(pspheres, &t.spheres)) || (e = upload(pnodes, &t.nodes)) || (e = upload(pmed, &t.mediums)) ||
+        (e = upload(plights, &t.lights))) {
+      t.release();
+      return e;
+    }
+    t.emin = c.wb->emin; t.depth = c.depth; t.root = L.remap(root_ref);
+    t.old_tri = L.old_of_new[0]; t.old_sphere = L.old_of_new[1]; t.old_quad = L.old_of_new[2];
+    return SOL_OK;
+  };
+  auto adopt_tree = [&](DevTree& t) {  // the scene takes ownership
+    s->nodes = t.nodes; s->wides = t.wides; s->leaf_refs = t.leaf_refs; s->tris = t.tris; s->tri_shade = t.tri_shade; s->quads = t.quads;
+    s->spheres = t.spheres; s->mediums = t.mediums; s->lights = t.lights;
+    s->old_index[0] = std::move(t.old_tri); s->old_index[1] = std::move(t.old_sphere); s->old_index[2] = std::move(t.old_quad);
+    DevScene& S = s->S;
+    S.nodes = t.nodes; S.wides = t.wides; S.leaf_refs = t.leaf_refs; S.tris = t.tris; S.tri_shade = t.tri_shade; S.quads = t.quads; S.spheres = t.spheres;
+    S.mediums = t.mediums; S.lights = t.lights; S.wroot = 0; S.wide_emin = t.emin; S.root = t.root;
+    s->tree_depth = t.depth;
+    t = DevTree{};
+  };
+  if ((rc = upload_tree(cands[0])) || (rc = upload(mats, &s->mats)) || (rc = upload(texs, &s->texs))) return rc;
+  {
+    std::vector<uint8_t> texels(d->texels, d->texels + d->n_texel_bytes);
+    if ((rc = upload(texels, &s->texels))) return rc;
+  }
   HIP_TRY(hipMalloc((void**)&s->work, 64));
   HIP_TRY(hipMalloc((void**)&s->counters, sizeof(DevCounters)));
   HIP_TRY(hipMemset(s->counters, 0, sizeof(DevCounters)));
@@ -535,10 +632,9 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   const auto t_probe0 = std::chrono::steady_clock::now();
 
   DevScene& S = s->S;
-  S.nodes = s->nodes; S.wides = s->wides; S.wroot = wroot; S.tris = s->tris; S.tri_shade = s->tri_shade; S.quads = s->quads; S.spheres = s->spheres;
-  S.mediums = s->mediums; S.mats = s->mats; S.texs = s->texs; S.texels = s->texels; S.lights = s->lights;
+  S.mats = s->mats; S.texs = s->texs; S.texels = s->texels;
   S.n_lights = d->n_lights;
-  S.root = root_ref;
+  adopt_tree(cands[0].dev);
   S.rxmin = root_box.v[0]; S.rxmax = root_box.v[1]; S.rymin = root_box.v[2]; S.rymax = root_box.v[3];
   S.rzmin = root_box.v[4]; S.rzmax = root_box.v[5];
   S.width = d->width; S.height = d->height; S.shader = d->shader_kind; S.max_depth = d->max_depth;
@@ -564,39 +660,51 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   if (const char* ps = std::getenv("SOL_WF_SLOTS")) s->wf_slots = std::max(4096, std::atoi(ps));
   if (const char* ps = std::getenv("SOL_WF_MIN_ITEMS")) s->wf_min_items = (uint32_t)std::max(0, std::atoi(ps));
   s->has_medium = d->n_mediums > 0;
-  s->tree_depth = tree_depth;
   s->blocks_x = (d->width + SOL_TILE - 1) / SOL_TILE;
   s->blocks_y = (d->height + SOL_TILE - 1) / SOL_TILE;
   if ((rc = set_partition(s, 0, 1))) return rc;
+  {  // a null table would be a GPU memory fault at the first launch, not an error code: refuse here
+    const void* tables[] = {S.nodes, S.wides, S.leaf_refs, S.tris, S.tri_shade, S.quads, S.spheres, S.mediums, S.mats, S.texs, S.texels, S.lights};
+    for (const void* p : tables)
+      if (!p) return fail(SOL_EDEVICE, "internal error: a device table of the scene is missing");
+  }
+  s->tree_name = cands[0].name;
   if (calibrate) {
     // Probe every candidate tree with a counted render of 16 samples per pixel over ~256 pixel blocks spread across the image
     // and keep the one with the least search work (a wide-node visit weighs ~2.5 primitive tests, by instruction count).
     // Images do not depend on the tree, the counters are deterministic, so is the choice.
-    cands[0].dev = s->wides;
-    auto free_cands = [&](size_t keep) {  // candidate 0's tree belongs to the handle (s->wides)
-      for (size_t k = 1; k < cands.size(); ++k)
-        if (k != keep && cands[k].dev) { hipFree(cands[k].dev); cands[k].dev = nullptr; }
-    };
+    auto free_cands = [&]() { for (auto& c : cands) c.dev.release(); };
     for (size_t k = 1; k < cands.size(); ++k)
-      if ((rc = upload(cands[k].wb->out, &cands[k].dev))) { free_cands(0); return rc; }
+      if ((rc = upload_tree(cands[k]))) { free_cands(); return rc; }
     const uint32_t nb = s->blocks_x * s->blocks_y;
     rc = set_partition(s, 0, (int)std::max(1u, nb / 256u));
-    size_t pick = 0;
+    size_t pick = 0, current = 0;  // `current`: the candidate whose arrays the scene holds at the moment
+    auto swap_in = [&](size_t k) {  // hand the scene's tree back to its candidate, adopt candidate k's
+      if (k == current) return;
+      DevTree& back = cands[current].dev;
+      back.nodes = s->nodes; back.wides = s->wides; back.leaf_refs = s->leaf_refs; back.tris = s->tris; back.tri_shade = s->tri_shade;
+      back.quads = s->quads; back.spheres = s->spheres; back.mediums = s->mediums; back.lights = s->lights;
+      back.emin = S.wide_emin; back.depth = s->tree_depth; back.root = S.root;
+      back.old_tri = std::move(s->old_index[0]); back.old_sphere = std::move(s->old_index[1]); back.old_quad = std::move(s->old_index[2]);
+      adopt_tree(cands[k].dev);
+      current = k;
+    };
     for (size_t k = 0; k < cands.size() && !rc; ++k) {
-      S.wides = cands[k].dev; S.wroot = cands[k].wroot; s->tree_depth = cands[k].depth;
+      swap_in(k);
       if (!(rc = sol_clear(s)) && !(rc = render_probe(s)))
         cands[k].cost = 2.5 * (double)s->stats.node_visits + (double)(s->stats.sphere_tests + s->stats.quad_tests + s->stats.triangle_tests);
       if (!rc && cands[k].cost < cands[pick].cost) pick = k;
     }
     if (std::getenv("SOL_VERBOSE")) {
       std::fprintf(stderr, "[solstrale] world tree probe:");
-      for (auto& c : cands) std::fprintf(stderr, " %s %.4g (%zu nodes)", c.name.c_str(), c.cost, c.wb->out.size());
+      for (auto& c : cands) std::fprintf(stderr, " %s %.4g (%zu nodes)", c.name.c_str(), c.cost, c.lay.nodes.size());
       std::fprintf(stderr, " -> %s\n", cands[pick].name.c_str());
     }
-    if (rc) { S.wides = s->wides; free_cands(0); return rc; }
-    free_cands(pick);
-    if (pick != 0) { hipFree(s->wides); s->wides = cands[pick].dev; }
-    S.wides = s->wides; S.wroot = cands[pick].wroot; s->tree_depth = cands[pick].depth;
+    if (hipStreamSynchronize(s->stream) != hipSuccess && !rc) rc = SOL_EDEVICE;
+    swap_in(pick);
+    s->tree_name = cands[pick].name;
+    free_cands();
+    if (rc) return rc;
     s->stats = SolStats{};
     if ((rc = set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1046,6 +1154,15 @@ int sol_debug_path(SolScene* s, uint32_t x, uint32_t y, uint32_t sample, uint64_
   hipFree(dout);
   if (dspill) hipFree(dspill);
   if (e != hipSuccess) return fail(SOL_EDEVICE, "sol_debug_path: %s", hipGetErrorString(e));
+  for (uint32_t r = 0; r < max_rows && rows[r * 12 + 3] != -1.0f; ++r) {  // hit references: device order -> the caller's indices
+    uint32_t ref;
+    std::memcpy(&ref, &rows[r * 12 + 7], 4);
+    const int a = WideLayout::arr(SOL_REF_KIND(ref));
+    if (a >= 0 && SOL_REF_INDEX(ref) < s->old_index[a].size()) {
+      ref = SOL_MAKE_REF(SOL_REF_KIND(ref), s->old_index[a][SOL_REF_INDEX(ref)]);
+      std::memcpy(&rows[r * 12 + 7], &ref, 4);
+    }
+  }
   return SOL_OK;
 }
 

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256) sol_eval_kernel(uint32_t fn, const float*
     }
     case 6: {  // triangle: v0(3), e1(3), e2(3), o(3), dir(3), tmin, tmax -> hit, t, u, v
       DTri T; T.v0x = x[0]; T.v0y = x[1]; T.v0z = x[2]; T.e1x = x[3]; T.e1y = x[4]; T.e1z = x[5]; T.e2x = x[6]; T.e2y = x[7];
-      T.e2z = x[8]; T.dfs = 0; T.mat = 0; T.pad = 0;
+      T.e2z = x[8]; T.dfs = 0; T.mat = 0; T.area = 0.f;
       float t = 0.f, u = 0.f, v = 0.f;
       bool h = tri_test(T, mk3(x[9], x[10], x[11]), mk3(x[12], x[13], x[14]), x[15], x[16], t, u, v);
       y[0] = h ? 1.f : 0.f; y[1] = h ? t : 0.f; y[2] = h ? u : 0.f; y[3] = h ? v : 0.f;

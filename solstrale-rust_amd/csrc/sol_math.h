@@ -14,6 +14,35 @@
 
 #define DEV __device__ __forceinline__
 
+// Scene pointers reach the device code through a DevScene record read from memory, so the compiler sees them as generic
+// ("flat") pointers: every access becomes flat_load, which counts against BOTH vmcnt and lgkmcnt - each wait for a node or a
+// triangle then also drains the queue of the LDS traversal stack - and pays the aperture check. They are all global
+// (hipMalloc). Neither an address-space round trip nor an is_shared/is_private assumption survives to the backend; what does
+// is a load THROUGH an address-space-1 pointer, so every scene record is fetched with these helpers (global_load_dword*).
+#define SOL_AS1 __attribute__((address_space(1)))
+typedef float sol_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t sol_v4u __attribute__((ext_vector_type(4)));
+DEV float4 ldg_f4(const void* p) {
+  const sol_v4f v = *(const SOL_AS1 sol_v4f*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+DEV uint4 ldg_u4(const void* p) {
+  const sol_v4u v = *(const SOL_AS1 sol_v4u*)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+DEV uint32_t ldg_u32(const void* p) { return *(const SOL_AS1 uint32_t*)p; }
+DEV int32_t ldg_i32(const void* p) { return *(const SOL_AS1 int32_t*)p; }
+DEV uint8_t ldg_u8(const void* p) { return *(const SOL_AS1 uint8_t*)p; }
+// a whole 16-byte-aligned record (sizeof a multiple of 16) by value
+template <typename T>
+DEV T ldg_rec(const T* p) {
+  static_assert(sizeof(T) % 16 == 0 && alignof(T) >= 16, "device records are 16-byte multiples");
+  union { T rec; sol_v4u q[sizeof(T) / 16]; } u;
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 16; ++k) u.q[k] = ((const SOL_AS1 sol_v4u*)p)[k];
+  return u.rec;
+}
+
 // Correctly rounded fp32 square root. `sqrtf` lowers to v_sqrt_f32 plus the fix-up sequence (16 instructions);
 // `__fsqrt_rn` on ROCm 7.2 is the bare 1-ulp v_sqrt_f32 despite its name (measured: 15 % of results differ from IEEE).
 DEV float sol_sqrt(float x) { return sqrtf(x); }

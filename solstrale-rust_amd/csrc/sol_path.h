@@ -153,7 +153,7 @@ DEV bool decode_item_ordered(const DevScene& S, const RenderParams& P, uint32_t 
     it.chunk = q / rest;
     k = S.n_first + (q - it.chunk * rest);
   }
-  const uint32_t lb = S.block_order ? S.block_order[k] : k;
+  const uint32_t lb = S.block_order ? ldg_u32(S.block_order + k) : k;
   it.slot = lb * 64u + pin;
   const uint32_t b = lb * P.world + P.rank;
   const uint32_t by = b / P.blocks_x, bx = b - by * P.blocks_x;

@@ -37,8 +37,8 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
   const uint32_t gtid = blockIdx.x * SOL_WG + tid;
   const uint32_t lane = tid & 63u;
   Stack st;
-  st.lds = lds_stack + tid;
-  st.spill = spill + gtid;
+  st.lds = (lds_u32*)lds_stack + tid;
+  st.spill = (SOL_AS1 uint32_t*)spill + gtid;
   st.stride = P.total_threads;
   st.depth = SOL_LDS_STACK;
   Counters cnt = {};
@@ -84,7 +84,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         const uint32_t n_need = (uint32_t)__popcll(need), my = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
         // volatile: the leader's stores and every lane's loads must stay real LDS accesses in program order (one wave's LDS
         // operations execute in order; without it the compiler may forward a stale value to the non-leader lanes)
-        volatile uint32_t* res = reservoir[tid >> 6];
+        volatile lds_u32* res = (volatile lds_u32*)reservoir[tid >> 6];
         const uint32_t next = res[0], left = res[1] - next;
         uint32_t fresh = 0;
         if (n_need > left) {  // take what is left, then continue in a fresh block of 64
@@ -111,7 +111,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         alive = true;
       }
       // world.hit(ray, RAY_INTERVAL) (src/renderer/mod.rs:165)
-      trav_begin(t, p.o, p.d, RAY_MIN_F, inf, SOL_WORLD_ROOT(S), S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
+      trav_begin<!SOL_WORLD_BINARY>(t, p.o, p.d, RAY_MIN_F, inf, SOL_WORLD_ROOT(S), S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
       in_flight = true;
     }
     // ---- search: one step per turn for every lane that has one. The wave leaves for the shading block when too few of
@@ -164,8 +164,8 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
   const uint32_t wave = blockIdx.x * (SOL_WG / 64) + wave_in_wg;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   Stack st;
-  st.lds = lds_stack + tid;
-  st.spill = spill + gtid;
+  st.lds = (lds_u32*)lds_stack + tid;
+  st.spill = (SOL_AS1 uint32_t*)spill + gtid;
   st.stride = P.total_threads;
   st.depth = SOL_LDS_STACK;
   uint16_t* queue = lds_queue + wave_in_wg * SOL_POOL_MAX;
@@ -284,7 +284,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
               rng_medium.k0 = __float_as_uint(r2.w); rng_medium.k1 = __float_as_uint(r3.w);
               depth_medium = __float_as_uint(r1.w) >> 8;
             }
-            trav_begin(t, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), RAY_MIN_F, inf, SOL_WORLD_ROOT(S), S.rxmin, S.rxmax, S.rymin,
+            trav_begin<!SOL_WORLD_BINARY>(t, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), RAY_MIN_F, inf, SOL_WORLD_ROOT(S), S.rxmin, S.rxmax, S.rymin,
                        S.rymax, S.rzmin, S.rzmax, 0);
             have = true;
           }
@@ -314,8 +314,8 @@ sol_debug_path_kernel(const DevScene S, const RenderParams P, uint32_t px, uint3
   __shared__ uint32_t lds_stack[SOL_LDS_STACK * SOL_WG];
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   Stack st;
-  st.lds = lds_stack;
-  st.spill = spill;
+  st.lds = (lds_u32*)lds_stack;
+  st.spill = (SOL_AS1 uint32_t*)spill;
   st.stride = P.total_threads;
   st.depth = SOL_LDS_STACK;
   Counters cnt = {};

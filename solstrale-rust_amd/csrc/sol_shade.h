@@ -17,7 +17,7 @@ struct Surface {
 // Texture::color (src/material/texture.rs:121-123,170-179) + rgb_to_vec3 (src/util/rgb_color.rs:37-43)
 template <bool COUNT>
 DEV f3 tex_color(const DevScene& S, int id, float u, float v, Counters& cnt) {
-  const DTex T = S.texs[id];
+  const DTex T = ldg_rec(S.texs + id);
   if (T.kind == SOL_TEX_SOLID) return mk3(T.r, T.g, T.b);
   if (COUNT) cnt.texel_fetches++;
   float au = fabsf(u), av = fabsf(v);
@@ -30,7 +30,7 @@ DEV f3 tex_color(const DevScene& S, int id, float u, float v, Counters& cnt) {
   yi = min(yi, T.h - 1u);
   const uint8_t* px = S.texels + T.offset + ((size_t)yi * T.w + xi) * 3;
   const float s = (float)(1.0 / 255.);
-  return mk3((float)px[0] * s, (float)px[1] * s, (float)px[2] * s);
+  return mk3((float)ldg_u8(px) * s, (float)ldg_u8(px + 1) * s, (float)ldg_u8(px + 2) * s);
 }
 
 // Geometry of the closest hit, recomputed from (ray, t, u, v) with the formulas of the primitives' `hit`.
@@ -41,7 +41,7 @@ DEV void build_surface(const DevScene& S, f3 o, f3 d, const Hit& h, const Rng& r
   sf.p = o + d * h.t;  // Ray::at (geo/mod.rs:288-290)
   if (kind == SOL_REF_TRIANGLE) {  // triangle.rs:145-172
     const float4* sp = reinterpret_cast<const float4*>(S.tri_shade + idx);
-    const float4 a = sp[0], b = sp[1], c = sp[2], e = sp[3];
+    const float4 a = ldg_f4(sp), b = ldg_f4(sp + 1), c = ldg_f4(sp + 2), e = ldg_f4(sp + 3);
     float uv0 = 1.0f - h.u - h.v;
     sf.u = uv0 * b.w + h.u * e.x + h.v * e.z;
     sf.v = uv0 * c.w + h.u * e.y + h.v * e.w;
@@ -49,9 +49,9 @@ DEV void build_surface(const DevScene& S, f3 o, f3 d, const Hit& h, const Rng& r
     sf.front = dot3(d, n) < 0.0f;
     if (!sf.front) n = neg3(n);
     sf.onb = Onb{mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), n};
-    sf.mat = S.tris[idx].mat;
+    sf.mat = (int32_t)__float_as_uint(a.w);  // DTriShade::mat
   } else if (kind == SOL_REF_QUAD) {  // quad.rs:175-193
-    const DQuad Q = S.quads[idx];
+    const DQuad Q = ldg_rec(S.quads + idx);
     f3 n = mk3(Q.nx, Q.ny, Q.nz);
     sf.front = dot3(d, n) < 0.0f;
     if (!sf.front) n = neg3(n);
@@ -59,11 +59,11 @@ DEV void build_surface(const DevScene& S, f3 o, f3 d, const Hit& h, const Rng& r
     sf.u = h.u; sf.v = h.v;
     sf.mat = Q.mat;
   } else if (kind == SOL_REF_SPHERE) {  // sphere.rs:83-107,134-140
-    const DSphere Sp = S.spheres[idx];
+    const DSphere Sp = ldg_rec(S.spheres + idx);
     f3 n = sf.p - mk3(Sp.cx, Sp.cy, Sp.cz);
     f3 normal = unit3(n);
     sf.mat = Sp.mat;
-    if (S.mats[Sp.mat].flags & DMAT_NEEDS_UV) {  // uv and tangents are consumed only by image textures
+    if (ldg_u32(&S.mats[Sp.mat].flags) & DMAT_NEEDS_UV) {  // uv and tangents are consumed only by image textures
       float theta = acos_r(-normal.y);
       float phi = -atan2_r(normal.z, normal.x) + SOL_PI;
       sf.u = phi / (2.0f * SOL_PI);
@@ -82,7 +82,7 @@ DEV void build_surface(const DevScene& S, f3 o, f3 d, const Hit& h, const Rng& r
     sf.onb = Onb{mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f), medium_normal(rng, idx, depth)};
     sf.u = sf.v = 0.0f;
     sf.front = false;
-    sf.mat = S.mediums[idx].mat;
+    sf.mat = ldg_i32(&S.mediums[idx].mat);
   }
 }
 
@@ -90,8 +90,8 @@ DEV void build_surface(const DevScene& S, f3 o, f3 d, const Hit& h, const Rng& r
 // transform_normal_by_map (:386-389); applied to the closest hit only (DESIGN.md "Deviations").
 template <bool COUNT>
 DEV f3 transformed_normal(const DevScene& S, int mid, const Surface& sf, Rng& rng, Counters& cnt) {
-  DMat m = S.mats[mid];
-  for (int guard = 0; guard < 16 && m.kind == SOL_MAT_BLEND; ++guard) m = S.mats[rnd(rng) > m.param ? m.m1 : m.m2];
+  DMat m = ldg_rec(S.mats + mid);
+  for (int guard = 0; guard < 16 && m.kind == SOL_MAT_BLEND; ++guard) m = ldg_rec(S.mats + (rnd(rng) > m.param ? m.m1 : m.m2));
   if (m.kind <= SOL_MAT_DIELECTRIC && m.normal >= 0) {
     f3 n = tex_color<COUNT>(S, m.normal, sf.u, sf.v, cnt) * 2.0f - mk3(1.f, 1.f, 1.f);
     return onb_local(sf.onb, n);
@@ -106,7 +106,7 @@ DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Co
   const uint32_t kind = SOL_REF_KIND(ref), idx = SOL_REF_INDEX(ref);
   const float inf = __builtin_huge_valf();
   if (kind == SOL_REF_QUAD) {
-    const DQuad Q = S.quads[idx];
+    const DQuad Q = ldg_rec(S.quads + idx);
     if (COUNT) cnt.quad_tests++;
     float t, u, v;
     if (!quad_test(Q, origin, dir, RAY_MIN_F, inf, t, u, v)) return 0.0f;
@@ -117,8 +117,8 @@ DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Co
     return ds / (cosine * Q.area);
   }
   if (kind == SOL_REF_TRIANGLE) {
-    const DTri T = S.tris[idx];
-    const DTriShade Ts = S.tri_shade[idx];
+    const DTri T = ldg_rec(S.tris + idx);
+    const DTriShade Ts = ldg_rec(S.tri_shade + idx);
     if (COUNT) cnt.triangle_tests++;
     float t, u, v;
     if (!tri_test(T, origin, dir, RAY_MIN_F, inf, t, u, v)) return 0.0f;
@@ -126,10 +126,10 @@ DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Co
     if (!(dot3(dir, n) < 0.0f)) n = neg3(n);
     float ds = t * t * len2(dir);
     float cosine = fabsf(dot3(dir, n) / len3(dir));
-    return ds / (cosine * Ts.area);
+    return ds / (cosine * T.area);
   }
   if (kind == SOL_REF_SPHERE) {
-    const DSphere Sp = S.spheres[idx];
+    const DSphere Sp = ldg_rec(S.spheres + idx);
     if (COUNT) cnt.sphere_tests++;
     float t;
     if (!sphere_test(Sp, origin, dir, RAY_MIN_F, inf, S.sphere_slack, t)) return 0.0f;
@@ -143,16 +143,16 @@ DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Co
 DEV f3 light_random_direction(const DevScene& S, uint32_t ref, f3 origin, Rng& rng) {
   const uint32_t kind = SOL_REF_KIND(ref), idx = SOL_REF_INDEX(ref);
   if (kind == SOL_REF_QUAD) {
-    const DQuad Q = S.quads[idx];
+    const DQuad Q = ldg_rec(S.quads + idx);
     float r1 = rnd(rng), r2 = rnd(rng);
     return mk3(Q.qx, Q.qy, Q.qz) + mk3(Q.ux, Q.uy, Q.uz) * r1 + mk3(Q.vx, Q.vy, Q.vz) * r2 - origin;
   }
   if (kind == SOL_REF_TRIANGLE) {
-    const DTri T = S.tris[idx];
+    const DTri T = ldg_rec(S.tris + idx);
     float r1 = rnd(rng), r2 = rnd(rng);
     return mk3(T.v0x, T.v0y, T.v0z) + mk3(T.e1x, T.e1y, T.e1z) * r1 + mk3(T.e2x, T.e2y, T.e2z) * r2 - origin;
   }
-  const DSphere Sp = S.spheres[idx];
+  const DSphere Sp = ldg_rec(S.spheres + idx);
   f3 direction = mk3(Sp.cx, Sp.cy, Sp.cz) - origin;
   Onb uvw = onb_new(direction);
   float ds = len2(direction);
@@ -166,12 +166,12 @@ DEV f3 light_random_direction(const DevScene& S, uint32_t ref, f3 origin, Rng& r
 template <bool COUNT>
 DEV float container_pdf_value(const DevScene& S, f3 origin, f3 dir, Counters& cnt) {  // pdf.rs:89-96
   float sum = 0.0f;
-  for (uint32_t i = 0; i < S.n_lights; ++i) sum += light_pdf_value<COUNT>(S, S.lights[i], origin, dir, cnt);
+  for (uint32_t i = 0; i < S.n_lights; ++i) sum += light_pdf_value<COUNT>(S, ldg_u32(S.lights + i), origin, dir, cnt);
   return sum / (float)S.n_lights;
 }
 DEV f3 container_pdf_generate(const DevScene& S, f3 origin, Rng& rng) {  // pdf.rs:98-101
   uint32_t i = rnd_index(rng, S.n_lights);
-  return light_random_direction(S, S.lights[i], origin, rng);
+  return light_random_direction(S, ldg_u32(S.lights + i), origin, rng);
 }
 DEV f3 random_in_unit_sphere(Rng& rng) {  // vec3.rs:380-392 (bound never reached: (1-pi/6)^80)
   f3 p = mk3(0.f, 0.f, 0.f);
@@ -208,8 +208,8 @@ struct Scatter {
 // :396-410 Isotropic, :430-436 Blend)
 template <bool COUNT>
 DEV void scatter(const DevScene& S, f3 ray_dir, const Surface& sf, Rng& rng, Scatter& sc, Counters& cnt) {
-  DMat m = S.mats[sf.mat];
-  for (int guard = 0; guard < 16 && m.kind == SOL_MAT_BLEND; ++guard) m = S.mats[rnd(rng) > m.param ? m.m1 : m.m2];
+  DMat m = ldg_rec(S.mats + sf.mat);
+  for (int guard = 0; guard < 16 && m.kind == SOL_MAT_BLEND; ++guard) m = ldg_rec(S.mats + (rnd(rng) > m.param ? m.m1 : m.m2));
   if (COUNT) cnt.shades++;
   sc.has_af = false; sc.af = 0.0f; sc.probability = 0.0f; sc.dir = mk3(0.f, 0.f, 0.f);
   if (m.kind == SOL_MAT_LAMBERTIAN) {

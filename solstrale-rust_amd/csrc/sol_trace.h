@@ -13,7 +13,7 @@
 #include "sol_math.h"
 #include "sol_types.h"
 
-// The world (searches with t >= 0.001) is walked through the 8-wide quantised tree; -DSOL_WORLD_BINARY=true builds the
+// The world (searches with t >= 0.001) is walked through the 7-wide quantised tree; -DSOL_WORLD_BINARY=true builds the
 // A/B variant that walks the 2-wide DNode tree instead (same results).
 #define SOL_WORLD_ROOT(S) (SOL_WORLD_BINARY ? (S).root : (S).wroot)
 
@@ -44,25 +44,29 @@ DEV void phase_tick(Counters& cnt, int ph) {
   }
 }
 
+// The two halves of the stack live in different address spaces and are typed so: a pointer chosen between them at run time
+// would be generic, and the pop of EVERY step a flat_load (vmcnt + lgkmcnt, aperture check) instead of a ds_read.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct Stack {
-  uint32_t* lds;     // base of this workgroup's [depth][SOL_WG] array, already offset by the lane
-  uint32_t* spill;   // base of the global spill area, already offset by the global thread id
-  uint32_t stride;   // total threads (spill stride between levels)
-  int depth;         // entries per lane kept in LDS; deeper entries go to the spill area
+  lds_u32* lds;              // base of this workgroup's [depth][SOL_WG] array, already offset by the lane
+  SOL_AS1 uint32_t* spill;   // base of the global spill area, already offset by the global thread id
+  uint32_t stride;           // total threads (spill stride between levels)
+  int depth;                 // entries per lane kept in LDS; deeper entries go to the spill area
 };
-DEV void stack_push(const Stack& s, int& sp, uint32_t v) {
-  if (sp < s.depth) s.lds[sp * SOL_WG] = v;
-  else s.spill[(size_t)(sp - s.depth) * s.stride] = v;
-  sp++;
-}
 DEV void stack_store(const Stack& s, int level, uint32_t v) {
   if (level < s.depth) s.lds[level * SOL_WG] = v;
   else s.spill[(size_t)(level - s.depth) * s.stride] = v;
 }
+DEV void stack_push(const Stack& s, int& sp, uint32_t v) {
+  stack_store(s, sp, v);
+  sp++;
+}
 DEV uint32_t stack_pop(const Stack& s, int& sp) {
   sp--;
-  if (sp < s.depth) return s.lds[sp * SOL_WG];
-  return s.spill[(size_t)(sp - s.depth) * s.stride];
+  uint32_t v;
+  if (sp < s.depth) v = s.lds[sp * SOL_WG];
+  else v = s.spill[(size_t)(sp - s.depth) * s.stride];
+  return v;
 }
 
 // Aabb::hit (src/geo/mod.rs:159-188): slab test over [0, inf); fmaxf/fminf return the non-NaN operand like Rust's
@@ -146,24 +150,30 @@ DEV bool better(float t, uint32_t dfs, const Hit& h) {
   return t < h.t || (t == h.t && (SOL_REF_KIND(h.ref) == SOL_REF_NONE || dfs > h.dfs));
 }
 
-// Visit order of the 8-wide tree: kWideFar[octant] = {slots 0-3, slots 4-7}, byte i = mask of the slots j that come after
-// slot i for a ray of that direction octant, i.e. (j ^ octant) > (i ^ octant).
-static __device__ const uint2 kWideFar[8] = {
-    {0xF0F8FCFEu, 0x0080C0E0u}, {0xF4F0FDFCu, 0x4000D0C0u}, {0xF3FBF0F2u, 0x30B00020u}, {0xF7F3F1F0u, 0x70301000u},
-    {0x00080C0Eu, 0x0F8FCFEFu}, {0x04000D0Cu, 0x4F0FDFCFu}, {0x030B0002u, 0x3FBF0F2Fu}, {0x07030100u, 0x7F3F1F0Fu}};
-
 // State of one closest-hit search.
+//
+// Searches of the 2-wide tree (constant-medium boundaries; BINARY) keep one reference per stack entry and `cur` = the
+// reference being visited. Searches of the 7-wide tree (the world) keep GROUPS, after Ylitie, Karras & Laine (2017, sec. 5):
+//   node group  g0 = base_inner | ordered hits << 24,  g1 = imask  - the inner children of one node that the ray's slab test
+//               hit and that have not been visited yet. "Ordered": bit p stands for slot p ^ octant, so the lowest set bit is
+//               the nearest child. Visiting a child pushes what is left of its parent's group: ONE two-dword stack entry per
+//               level instead of one entry per child (the first layout: eight ds_write_b32 and ~70 placement instructions per
+//               visit).
+//   prim group  pg = base_prim | hit leaf slots << 24,  aux = octant | leaf kind << 3 | lmask << 5 - the hit primitives of
+//               the node visited last; they are tested before the search descends further.
+// `cur` is only the status of such a search: REF_DONE when it is over, 0 while it runs.
 struct Trav {
   f3 o, d, inv;
   float tmin;
-  uint32_t cur;  // reference being visited, REF_DONE when the search is over
+  uint32_t cur;
   int sp, sp_base;
-  uint2 far;     // kWideFar[ray octant] (8-wide searches only)
+  uint32_t g0, g1, pg, aux;  // (7-wide searches only)
   Hit h;
 };
 
 // Starts a search of `root` over [tmin, tmax]; (bxmin..bzmax) is root's own box, tested first when root is a node
-// (Bvh::hit, bvh.rs:166).
+// (Bvh::hit, bvh.rs:166). WIDE: root is an index into DevScene::wides, else a reference into the 2-wide tree.
+template <bool WIDE>
 DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, float bxmin, float bxmax, float bymin,
                     float bymax, float bzmin, float bzmax, int sp_base) {
   t.o = o; t.d = d; t.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // Ray::new (geo/mod.rs:277-285)
@@ -173,19 +183,21 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
   t.h.dfs = 0;
   t.h.u = t.h.v = 0.0f;
   t.sp = t.sp_base = sp_base;
-  t.cur = root;
-  t.far = make_uint2(0u, 0u);
+  t.cur = WIDE ? 0u : root;
+  // the root as a group of one: imask 0 makes every slot's rank 0, so the "child" picked from it is node `root` itself
+  t.g0 = root | (1u << 24);
+  t.g1 = 0u;
+  t.pg = 0u;
+  t.aux = (__builtin_signbitf(t.inv.x) ? 4u : 0u) | (__builtin_signbitf(t.inv.y) ? 2u : 0u) | (__builtin_signbitf(t.inv.z) ? 1u : 0u);
   // A ray with a NaN in its origin or direction cannot hit anything: every primitive test ends in a comparison with NaN,
   // which is false (the reference returns None the same way, after visiting every box - Aabb::hit ignores NaN). Such rays
   // occur a few times per 10^8 samples; without this exit one lane walks the whole tree and tests every primitive.
   if (isnan(d.x) || isnan(d.y) || isnan(d.z) || isnan(o.x) || isnan(o.y) || isnan(o.z)) { t.cur = REF_DONE; return; }
-  if (SOL_REF_KIND(root) == SOL_REF_NODE || SOL_REF_KIND(root) == SOL_REF_WIDE) {
+  if (WIDE || SOL_REF_KIND(root) == SOL_REF_NODE) {
     float te;
     if (!slab(bxmin, bxmax, bymin, bymax, bzmin, bzmax, o, t.inv, __builtin_signbitf(t.inv.x), __builtin_signbitf(t.inv.y),
               __builtin_signbitf(t.inv.z), te))
       t.cur = REF_DONE;
-    if (SOL_REF_KIND(root) == SOL_REF_WIDE)
-      t.far = kWideFar[(__builtin_signbitf(t.inv.x) ? 4u : 0u) | (__builtin_signbitf(t.inv.y) ? 2u : 0u) | (__builtin_signbitf(t.inv.z) ? 1u : 0u)];
   }
 }
 
@@ -208,105 +220,174 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
     const float tx = fminf(fminf(tfx, tfy), fminf(tfz, cull_t));                                                        \
     hits |= (te <= tx) ? (1u << (i)) : 0u; /* an empty slot has an inverted box; at worst it yields a NONE ref (no-op) */ \
   }
-// Second pass. Children are visited in order of k = slot ^ octant (slots are octants of the node's split planes, so this
-// is front to back along the ray's direction signs). The nearest hit child becomes the current reference, the others go
-// on the stack with the nearest of them on top: level = sp + (number of hit children that are farther). "Farther than
-// slot i" is a fixed slot set per ray octant (kWideFar, one byte per slot), so a level costs and + popcount.
-// Fast form (whole node fits in the LDS part of the stack): branch-free - a child that was not hit is stored to a scratch
-// level above everything live, the nearest child is stored too (at sp + n - 1, the level the stack does not keep).
-#define SOL_WIDE_PLACE_FAST(i, refv, farw)                                                                   \
-  {                                                                                                          \
-    const uint32_t pos = __popc(hits & (((farw) >> (8 * ((i) & 3))) & 0xFFu));                                \
-    const uint32_t lvl = (hits & (1u << (i))) ? pos : 8u;                                                     \
-    base[lvl * SOL_WG] = (refv);                                                                             \
-    nearest = (lvl == n_hit - 1u) ? (refv) : nearest;                                                        \
+// Tests primitive `idx` of kind `kind` against the search's interval [tmin, best t] and keeps it when it is the better hit
+// (smaller t; among equal t the later one in depth-first leaf order, bvh.rs:172-178).
+template <bool COUNT, bool MEDIUM>
+DEV void prim_test(const DevScene& S, Trav& t, const Stack& st, uint32_t kind, uint32_t idx, const Rng& rng, uint32_t depth,
+                   Counters& cnt) {
+  const uint32_t ref = SOL_MAKE_REF(kind, idx);
+  if (kind == SOL_REF_TRIANGLE) {
+    const float4* tp = reinterpret_cast<const float4*>(S.tris + idx);
+    const float4 p0 = ldg_f4(tp), p1 = ldg_f4(tp + 1), p2 = ldg_f4(tp + 2);
+    DTri T;
+    T.v0x = p0.x; T.v0y = p0.y; T.v0z = p0.z; T.e1x = p0.w; T.e1y = p1.x; T.e1z = p1.y; T.e2x = p1.z; T.e2y = p1.w; T.e2z = p2.x;
+    const uint32_t dfs = __float_as_uint(p2.y);
+    if (COUNT) cnt.triangle_tests++;
+    float tt, u, v;
+    if (tri_test(T, t.o, t.d, t.tmin, t.h.t, tt, u, v) && better(tt, dfs, t.h)) { t.h.t = tt; t.h.ref = ref; t.h.dfs = dfs; t.h.u = u; t.h.v = v; }
+  } else if (kind == SOL_REF_SPHERE) {
+    const DSphere Sp = ldg_rec(S.spheres + idx);
+    if (COUNT) cnt.sphere_tests++;
+    float tt;
+    if (sphere_test(Sp, t.o, t.d, t.tmin, t.h.t, S.sphere_slack, tt) && better(tt, Sp.dfs, t.h)) { t.h.t = tt; t.h.ref = ref; t.h.dfs = Sp.dfs; }
+  } else if (kind == SOL_REF_QUAD) {
+    const DQuad Q = ldg_rec(S.quads + idx);
+    if (COUNT) cnt.quad_tests++;
+    float tt, u, v;
+    if (quad_test(Q, t.o, t.d, t.tmin, t.h.t, tt, u, v) && better(tt, Q.dfs, t.h)) { t.h.t = tt; t.h.ref = ref; t.h.dfs = Q.dfs; t.h.u = u; t.h.v = v; }
+  } else if (MEDIUM && kind == SOL_REF_MEDIUM) {
+    float tt;
+    const uint32_t dfs = ldg_u32(&S.mediums[idx].dfs);
+    if (medium_test<COUNT>(S, idx, t.o, t.d, t.tmin, t.h.t, tt, st, t.sp, rng, depth, cnt) && better(tt, dfs, t.h)) {
+      t.h.t = tt; t.h.ref = ref; t.h.dfs = dfs;
+    }
   }
-#define SOL_WIDE_PLACE(i, refv, farw)                                                                        \
-  if (hits & (1u << (i))) {                                                                                  \
-    const uint32_t pos = __popc(hits & (((farw) >> (8 * ((i) & 3))) & 0xFFu));                                \
-    if (pos == n_hit - 1u) cur = (refv);                                                                     \
-    else stack_store(st, t.sp + (int)pos, (refv));                                                           \
-  }
+}
 
-// One step: visits the node or primitive t.cur, then moves to the next reference (near child, or popped from the stack).
-// BINARY selects which inner-node kind this search walks: the 2-wide DNode tree (constant-medium boundaries, whose
-// search interval includes negative t) or the 8-wide DWide tree (the world).
+// One step of a search. BINARY selects which tree this search walks: the 2-wide DNode tree (constant-medium boundaries,
+// whose search interval includes negative t) or the 7-wide DWide tree (the world).
+//   2-wide: visits the node or primitive t.cur, then moves to the next reference (near child, or popped from the stack).
+//   7-wide: part 1 - a lane without pending primitives takes the nearest child of its node group (popping a group first when
+//   its own is used up), pushes the rest of the group, fetches that node (64 bytes) and tests its seven child boxes: a new node
+//   group and a new primitive group. Part 2 - a lane with pending primitives tests ONE of them. A lane so advances by up to
+//   two visits per step, while a wave whose lanes are spread over nodes and primitives pays for both parts anyway.
 template <bool COUNT, bool MEDIUM, bool BINARY>
 DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
+  phase_tick<COUNT>(cnt, 0);
+  if (!BINARY) {
+    const uint32_t oct = t.aux & 7u;
+    if ((t.pg >> 24) == 0u) {
+      uint32_t g0 = t.g0, g1 = t.g1;
+      if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
+        g1 = stack_pop(st, t.sp);
+        g0 = stack_pop(st, t.sp);
+      }
+      const uint32_t p = (uint32_t)__builtin_ctz(g0 >> 24);  // nearest: lowest bit in visit order
+      const uint32_t slot = p ^ oct;
+      g0 &= ~(1u << (24u + p));
+      const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc(g1 & ((1u << slot) - 1u));
+      if ((g0 >> 24) != 0u) {  // siblings left: one stack entry for all of them
+        stack_push(st, t.sp, g0);
+        stack_push(st, t.sp, g1);
+        if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
+      }
+      const bool sx = (oct & 4u) != 0u, sy = (oct & 2u) != 0u, sz = (oct & 1u) != 0u;
+      const float4* wp = reinterpret_cast<const float4*>(S.wides + idx);
+      const float4 h = ldg_f4(wp);
+      const uint4 qa = ldg_u4(wp + 1), qb = ldg_u4(wp + 2), qc = ldg_u4(wp + 3);
+      if (COUNT) cnt.node_visits++;
+#if defined(SOL_EXP_VMEM) || defined(SOL_EXP_VALU) || defined(SOL_EXP_LDS)
+      // Sensitivity probes (A/B builds only, tests/tools/variants.py): extra work per node visit that changes no result -
+      // SOL_EXP_VMEM more 16-byte loads of this node (L1 hits), SOL_EXP_VALU more vector instructions, SOL_EXP_LDS more LDS stores -
+      // to see which pipe the kernel's time follows.
+      {
+        uint32_t zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+#ifdef SOL_EXP_VMEM
+#pragma unroll
+        for (int k = 0; k < SOL_EXP_VMEM; ++k) { const uint4 x = ldg_u4(wp + zero + (k % 4)); asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
+#endif
+#ifdef SOL_EXP_VALU
+        float dummy = h.x;
+#pragma unroll
+        for (int k = 0; k < SOL_EXP_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy));
+        asm volatile("" ::"v"(dummy));
+#endif
+#ifdef SOL_EXP_LDS
+#pragma unroll
+        for (int k = 0; k < SOL_EXP_LDS; ++k) st.lds[(SOL_LDS_STACK - 1) * SOL_WG] = zero;  // (top level: scratch unless the stack is full)
+#endif
+      }
+#endif
+      const uint32_t meta = __float_as_uint(h.w);
+      const float scx = __uint_as_float(((meta & 31u) + S.wide_emin) << 23), scy = __uint_as_float((((meta >> 5) & 31u) + S.wide_emin) << 23);
+      const float scz = __uint_as_float((((meta >> 10) & 31u) + S.wide_emin) << 23);
+#ifdef SOL_NO_TCULL
+      const float cull_t = __builtin_huge_valf();
+#else
+      const float cull_t = t.h.t;  // t >= tmin > 0 in a world search
+#endif
+      uint32_t hits = 0u;
+      // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
+      // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
+      // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
+      const float ivx = __builtin_amdgcn_fmed3f(t.inv.x, -1e30f, 1e30f), ivy = __builtin_amdgcn_fmed3f(t.inv.y, -1e30f, 1e30f);
+      const float ivz = __builtin_amdgcn_fmed3f(t.inv.z, -1e30f, 1e30f);
+      const float ax = (h.x - t.o.x) * ivx, bx = scx * ivx;
+      const float ay = (h.y - t.o.y) * ivy, by = scy * ivy;
+      const float az = (h.z - t.o.z) * ivz, bz = scz * ivz;
+      // q words: qa = {lo_x[0..3], lo_x[4..7], lo_y[0..3], lo_y[4..7]}, qb = {lo_z.., lo_z.., hi_x.., hi_x..},
+      //          qc = {hi_y.., hi_y.., hi_z.., hi_z..}; near = the plane the ray meets first on that axis
+      const uint32_t nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
+      const uint32_t ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
+      const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
+      SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+      SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+      SOL_WIDE_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+      SOL_WIDE_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+      SOL_WIDE_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+      SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+      SOL_WIDE_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+      const uint32_t imask = (meta >> 15) & 0x7Fu, lmask = (meta >> 22) & 0x7Fu;
+      // inner hits into visit order: bit p <- bit p ^ octant (three conditional butterfly stages)
+      uint32_t ih = hits & imask;
+      ih = (oct & 1u) ? (((ih & 0x55u) << 1) | ((ih >> 1) & 0x55u)) : ih;
+      ih = (oct & 2u) ? (((ih & 0x33u) << 2) | ((ih >> 2) & 0x33u)) : ih;
+      ih = (oct & 4u) ? (((ih & 0x0Fu) << 4) | (ih >> 4)) : ih;
+      // base indices ride in the slot-7 bytes of the six plane arrays (lo x, y, z: inner; hi x, y, z: primitives)
+      const uint32_t base_inner = (qa.y >> 24) | ((qa.w >> 24) << 8) | ((qb.y >> 24) << 16);
+      const uint32_t base_prim = (qb.w >> 24) | ((qc.y >> 24) << 8) | ((qc.w >> 24) << 16);
+      t.g0 = base_inner | (ih << 24);
+      t.g1 = imask;
+      t.pg = base_prim | ((hits & lmask) << 24);
+      t.aux = oct | ((meta >> 29) << 3) | (lmask << 5);
+    }
+    // status for the callers' loops, and for the postponing rule below
+    const bool has_prim = (t.pg >> 24) != 0u;
+    const bool has_inner = !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);
+    if (!has_prim && !has_inner) { t.cur = REF_DONE; return; }
+#if SOL_PRIM_MIN > 1
+    // Postponed primitive tests: the lanes holding primitives wait while fewer than SOL_PRIM_MIN of the wave's lanes do and
+    // some lane still has an inner node to visit next turn; the primitive part then runs with more lanes enabled. Results do
+    // not depend on the order of the tests.
+    const unsigned long long inner_m = __ballot(has_inner), prim_m = __ballot(has_prim);
+    if (!has_prim) return;
+    if (inner_m != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) return;
+#else
+    if (!has_prim) return;
+#endif
+    const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
+    t.pg &= ~(1u << (24u + slot));
+    const uint32_t lmask = (t.aux >> 5) & 0x7Fu, lkind = (t.aux >> 3) & 3u;
+    uint32_t idx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(lmask & ((1u << slot) - 1u));
+    uint32_t kind = lkind == SOL_LEAF_TRIANGLES ? SOL_REF_TRIANGLE : lkind == SOL_LEAF_SPHERES ? SOL_REF_SPHERE : SOL_REF_QUAD;
+    if (lkind == SOL_LEAF_REFS) {  // mixed node: the reference is listed
+      const uint32_t r = ldg_u32(S.leaf_refs + idx);
+      kind = SOL_REF_KIND(r);
+      idx = SOL_REF_INDEX(r);
+    }
+    prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
+    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
+    return;
+  }
   uint32_t cur = t.cur;
   uint32_t kind = SOL_REF_KIND(cur);
-  phase_tick<COUNT>(cnt, 0);
-  // Part 1: an inner node, if the lane is at one; its nearest hit child (or, when no child is hit, the top of the stack)
-  // becomes `cur`. Part 2: a primitive, if `cur` is one now. A lane so advances by up to two visits per step, while a wave
-  // whose lanes are spread over nodes and primitives pays for both parts on every step anyway.
-  if (!BINARY && kind == SOL_REF_WIDE) {
-    const uint32_t idx = SOL_REF_INDEX(cur);
-    const bool sx = __builtin_signbitf(t.inv.x), sy = __builtin_signbitf(t.inv.y), sz = __builtin_signbitf(t.inv.z);
-    const float4* wp = reinterpret_cast<const float4*>(S.wides + idx);
-    const float4 h = wp[0];
-    const uint4 qa = *reinterpret_cast<const uint4*>(wp + 1), qb = *reinterpret_cast<const uint4*>(wp + 2);
-    const uint4 qc = *reinterpret_cast<const uint4*>(wp + 3);
-    const uint4 ra = *reinterpret_cast<const uint4*>(wp + 4), rb = *reinterpret_cast<const uint4*>(wp + 5);
-    if (COUNT) cnt.node_visits++;
-    const uint32_t meta = __float_as_uint(h.w);
-    const float scx = __uint_as_float((meta & 0xFFu) << 23), scy = __uint_as_float(((meta >> 8) & 0xFFu) << 23);
-    const float scz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
-#ifdef SOL_NO_TCULL
-    const float cull_t = __builtin_huge_valf();
-#else
-    const float cull_t = t.h.t;  // t >= tmin > 0 in a world search
-#endif
-    uint32_t hits = 0u;
-    // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
-    // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
-    // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
-    const float ivx = __builtin_amdgcn_fmed3f(t.inv.x, -1e30f, 1e30f), ivy = __builtin_amdgcn_fmed3f(t.inv.y, -1e30f, 1e30f);
-    const float ivz = __builtin_amdgcn_fmed3f(t.inv.z, -1e30f, 1e30f);
-    const float ax = (h.x - t.o.x) * ivx, bx = scx * ivx;
-    const float ay = (h.y - t.o.y) * ivy, by = scy * ivy;
-    const float az = (h.z - t.o.z) * ivz, bz = scz * ivz;
-    // q words: qa = {lo_x[0..3], lo_x[4..7], lo_y[0..3], lo_y[4..7]}, qb = {lo_z.., lo_z.., hi_x.., hi_x..},
-    //          qc = {hi_y.., hi_y.., hi_z.., hi_z..}; near = the plane the ray meets first on that axis
-    const uint32_t nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
-    const uint32_t ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
-    const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
-    SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, ra.x)
-    SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, ra.y)
-    SOL_WIDE_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, ra.z)
-    SOL_WIDE_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, ra.w)
-    SOL_WIDE_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, rb.x)
-    SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, rb.y)
-    SOL_WIDE_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, rb.z)
-    SOL_WIDE_CHILD(7, nx1, ny1, nz1, fx1, fy1, fz1, rb.w)
-    // keeps the loads of the references with the loads of the boxes (the compiler would sink them behind the branch, a
-    // second dependent memory round trip per node)
-    asm volatile("" ::"v"(ra.x), "v"(ra.y), "v"(ra.z), "v"(ra.w), "v"(rb.x), "v"(rb.y), "v"(rb.z), "v"(rb.w));
-    if (hits != 0u) {
-      const uint32_t n_hit = __popc(hits);
-      if (t.sp + 9 <= st.depth) {
-        uint32_t* base = st.lds + t.sp * SOL_WG;
-        uint32_t nearest = 0u;
-        SOL_WIDE_PLACE_FAST(0, ra.x, t.far.x) SOL_WIDE_PLACE_FAST(1, ra.y, t.far.x) SOL_WIDE_PLACE_FAST(2, ra.z, t.far.x)
-        SOL_WIDE_PLACE_FAST(3, ra.w, t.far.x) SOL_WIDE_PLACE_FAST(4, rb.x, t.far.y) SOL_WIDE_PLACE_FAST(5, rb.y, t.far.y)
-        SOL_WIDE_PLACE_FAST(6, rb.z, t.far.y) SOL_WIDE_PLACE_FAST(7, rb.w, t.far.y)
-        cur = nearest;
-      } else {  // the node may reach the spill area: generic stores
-        SOL_WIDE_PLACE(0, ra.x, t.far.x) SOL_WIDE_PLACE(1, ra.y, t.far.x) SOL_WIDE_PLACE(2, ra.z, t.far.x)
-        SOL_WIDE_PLACE(3, ra.w, t.far.x) SOL_WIDE_PLACE(4, rb.x, t.far.y) SOL_WIDE_PLACE(5, rb.y, t.far.y)
-        SOL_WIDE_PLACE(6, rb.z, t.far.y) SOL_WIDE_PLACE(7, rb.w, t.far.y)
-      }
-      t.sp += (int)n_hit - 1;
-      if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
-    } else {
-      cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
-    }
-    kind = SOL_REF_KIND(cur);
-  } else if (BINARY && kind == SOL_REF_NODE) {
+  if (kind == SOL_REF_NODE) {
     const uint32_t idx = SOL_REF_INDEX(cur);
     const bool sx = __builtin_signbitf(t.inv.x), sy = __builtin_signbitf(t.inv.y), sz = __builtin_signbitf(t.inv.z);
     const float4* np = reinterpret_cast<const float4*>(S.nodes + idx);
-    const float4 a = np[0], b = np[1], c = np[2];
-    const uint4 r = *reinterpret_cast<const uint4*>(np + 3);
+    const float4 a = ldg_f4(np), b = ldg_f4(np + 1), c = ldg_f4(np + 2);
+    const uint4 r = ldg_u4(np + 3);
     if (COUNT) cnt.node_visits++;
     // Culling: a box whose entry parameter lies beyond the best hit cannot hold a better one. The slab test clamps the
     // entry to 0 (origin inside the box), and a search over (-inf, inf) (constant-medium boundary) accepts hits at
@@ -340,48 +421,8 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     }
     kind = SOL_REF_KIND(cur);
   }
-  const bool is_inner = cur != REF_DONE && kind == (BINARY ? SOL_REF_NODE : SOL_REF_WIDE);
-#if SOL_PRIM_MIN > 1
-  // Postponed primitive tests (world search only): the lanes holding a primitive wait - keep it as their current reference -
-  // while fewer than SOL_PRIM_MIN of the wave's lanes do and some lane still has an inner node to visit next turn; the
-  // primitive part then runs with more lanes enabled. Results do not depend on the order of the tests.
-  unsigned long long inner_m = 0ull, prim_m = 0ull;
-  if (!BINARY) {
-    inner_m = __ballot(is_inner);
-    prim_m = __ballot(cur != REF_DONE && !is_inner);  // (counting per primitive kind instead was measured: no better)
-  }
-#endif
-  if (cur == REF_DONE || is_inner) { t.cur = cur; return; }
-#if SOL_PRIM_MIN > 1
-  if (!BINARY && inner_m != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) { t.cur = cur; return; }
-#endif
-  const uint32_t idx = SOL_REF_INDEX(cur);
-  if (kind == SOL_REF_TRIANGLE) {
-    const float4* tp = reinterpret_cast<const float4*>(S.tris + idx);
-    const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-    DTri T;
-    T.v0x = p0.x; T.v0y = p0.y; T.v0z = p0.z; T.e1x = p0.w; T.e1y = p1.x; T.e1z = p1.y; T.e2x = p1.z; T.e2y = p1.w; T.e2z = p2.x;
-    const uint32_t dfs = __float_as_uint(p2.y);
-    if (COUNT) cnt.triangle_tests++;
-    float tt, u, v;
-    if (tri_test(T, t.o, t.d, t.tmin, t.h.t, tt, u, v) && better(tt, dfs, t.h)) { t.h.t = tt; t.h.ref = cur; t.h.dfs = dfs; t.h.u = u; t.h.v = v; }
-  } else if (kind == SOL_REF_SPHERE) {
-    const DSphere Sp = S.spheres[idx];
-    if (COUNT) cnt.sphere_tests++;
-    float tt;
-    if (sphere_test(Sp, t.o, t.d, t.tmin, t.h.t, S.sphere_slack, tt) && better(tt, Sp.dfs, t.h)) { t.h.t = tt; t.h.ref = cur; t.h.dfs = Sp.dfs; }
-  } else if (kind == SOL_REF_QUAD) {
-    const DQuad Q = S.quads[idx];
-    if (COUNT) cnt.quad_tests++;
-    float tt, u, v;
-    if (quad_test(Q, t.o, t.d, t.tmin, t.h.t, tt, u, v) && better(tt, Q.dfs, t.h)) { t.h.t = tt; t.h.ref = cur; t.h.dfs = Q.dfs; t.h.u = u; t.h.v = v; }
-  } else if (MEDIUM && kind == SOL_REF_MEDIUM) {
-    float tt;
-    const uint32_t dfs = S.mediums[idx].dfs;
-    if (medium_test<COUNT>(S, idx, t.o, t.d, t.tmin, t.h.t, tt, st, t.sp, rng, depth, cnt) && better(tt, dfs, t.h)) {
-      t.h.t = tt; t.h.ref = cur; t.h.dfs = dfs;
-    }
-  }
+  if (cur == REF_DONE || kind == SOL_REF_NODE) { t.cur = cur; return; }
+  prim_test<COUNT, MEDIUM>(S, t, st, kind, SOL_REF_INDEX(cur), rng, depth, cnt);
   t.cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
 }
 
@@ -391,7 +432,7 @@ DEV void closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, uint
                      float bymin, float bymax, float bzmin, float bzmax, Hit& h, const Stack& st, int sp_base, const Rng& rng,
                      uint32_t depth, Counters& cnt) {
   Trav t;
-  trav_begin(t, o, d, tmin, tmax, root, bxmin, bxmax, bymin, bymax, bzmin, bzmax, sp_base);
+  trav_begin<!BINARY>(t, o, d, tmin, tmax, root, bxmin, bxmax, bymin, bymax, bzmin, bzmax, sp_base);
   while (t.cur != REF_DONE) trav_step<COUNT, MEDIUM, BINARY>(S, t, st, rng, depth, cnt);
   h = t.h;
 }
@@ -402,7 +443,7 @@ DEV void closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, uint
 template <bool COUNT>
 DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, float tmax, float& t_out, const Stack& st,
                      int sp, const Rng& rng, uint32_t depth, Counters& cnt) {
-  const DMedium M = S.mediums[midx];
+  const DMedium M = ldg_rec(S.mediums + midx);
   const float inf = __builtin_huge_valf();
   Hit h1, h2;
   closest_hit<COUNT, false, true>(S, o, d, -inf, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax, h1, st, sp,

@@ -3,7 +3,10 @@
 //   TreeBuilder  the reference-shaped binary tree (SolBvhNode, own box per node) -> DNode (child boxes in the parent): walked by
 //                the boundary searches of ConstantMedium and by the -DSOL_WORLD_BINARY=true A/B build;
 //   SahBuilder   a binned surface-area-heuristic rebuild of the WORLD's binary tree over the same primitives;
-//   WideBuilder  collapse of a binary tree into 8-wide nodes with 8-bit quantised child boxes (DWide), the tree every
+//   WideBuilder  collapse of a binary tree into 7-wide nodes with 8-bit quantised child boxes, in explicit form (XWide: one
+//                reference per child);
+//   WideLayout   the device form of that tree (DWide: 64 bytes, implicit child addresses): children of a node consecutive,
+//                primitive arrays permuted so that the primitives of a node are consecutive - the tree every
 //                world.hit(ray, [0.001, inf)) walks.
 // Why the device may walk another tree than the reference's: DESIGN.md 4, "tree independence". sol_world_tree_check
 // (sol_api.cpp) verifies the structure of what these builders produce.
@@ -131,12 +134,38 @@ struct TreeBuilder {
   }
 };
 
-// Collapses the binary device tree into 8-wide nodes with 8-bit quantised child boxes (DWide, sol_types.h). Pure layout:
+// Explicit form of a wide node (host only): grid origin, biased exponents of the three scales, the quantised planes laid
+// out as in DWide (slot 7 unused), one reference per slot (SOL_REF_WIDE = index into the XWide array, a primitive, or NONE).
+struct XWide {
+  float o[3];
+  uint32_t e[3];
+  uint32_t q[12];
+  uint32_t ref[8];
+};
+
+// Collapses the binary device tree into 7-wide nodes with 8-bit quantised child boxes (XWide). Pure layout:
 // every decoded child box CONTAINS the child's padded fp32 box (checked with the device's own decode arithmetic), so the
 // wide tree culls no ray that the binary tree would not; closest hits (t, tie rule on dfs_index) are identical.
 struct WideBuilder {
+  static constexpr int MAXC = SOL_WIDE_CHILDREN;  // children per node (slots 0 .. MAXC-1 of the eight octant slots)
   const std::vector<DNode>& bin;
-  std::vector<DWide> out;
+  std::vector<XWide> out;
+  // Exponents are stored in 5 bits relative to `emin` (DWide::meta): every scale of the tree lies in 2^[emin, emin + 31].
+  // set_exponent_range() derives emin from the root's extent (no box below is larger); smaller nodes than 2^emin * 255 use the
+  // coarser grid 2^emin (still containing, only less tight: 31 binary orders below the scene's size).
+  uint32_t emin = 1;
+  bool range_error = false;
+  void set_exponent_range(const Box& root_box) {
+    float ext = 0.f;
+    for (int a = 0; a < 3; ++a) {
+      const float e = root_box.v[2 * a + 1] - root_box.v[2 * a];
+      if (std::isfinite(e) && e > ext) ext = e;
+    }
+    int ex = -126;
+    if (ext > 0.f) std::frexp((ext + 8.f * pad) / 255.0f, &ex);
+    const int emax = std::min(254, std::max(1, ex + 127 + 1));  // one order of headroom for the pads added per level
+    emin = (uint32_t)std::max(1, emax - 31);
+  }
   uint32_t max_depth = 0;
   // surface-area estimate of a random ray's work: summed box areas of the children that are wide nodes / primitives
   // (a child is visited with probability ~ its area / the root's area)
@@ -188,22 +217,22 @@ struct WideBuilder {
     for (int i = 0; i <= 8; ++i) { d.c[i] = 0.; d.eff[i] = 0; d.split[i] = 0; }
     if (!hl && !hr) return;
     if (hl != hr) {  // a single child: the node vanishes (eff 0 = pass through)
-      for (int i = 1; i <= 8; ++i) d.c[i] = hl ? dp_t(n.left, lbox(n), i) : dp_t(n.right, rbox(n), i);
+      for (int i = 1; i <= MAXC; ++i) d.c[i] = hl ? dp_t(n.left, lbox(n), i) : dp_t(n.right, rbox(n), i);
       dp[m] = d;
       return;
     }
     const Box bl = lbox(n), br = rbox(n);
     double tl[9], tr[9], dist[9];
-    for (int i = 1; i <= 8; ++i) { tl[i] = dp_t(n.left, bl, i); tr[i] = dp_t(n.right, br, i); }
+    for (int i = 1; i <= MAXC; ++i) { tl[i] = dp_t(n.left, bl, i); tr[i] = dp_t(n.right, br, i); }
     Dp& e = dp[m];  // (dp may have been re-allocated? no: sized once above; re-take the reference after the recursion anyway)
-    for (int j = 2; j <= 8; ++j) {
+    for (int j = 2; j <= MAXC; ++j) {
       dist[j] = std::numeric_limits<double>::infinity();
       for (int k = 1; k < j; ++k)
         if (tl[k] + tr[j - k] < dist[j]) { dist[j] = tl[k] + tr[j - k]; e.split[j] = (uint8_t)k; }
     }
-    e.c[1] = NODE_COST * (double)area(unite(bl, br)) + dist[8];
+    e.c[1] = NODE_COST * (double)area(unite(bl, br)) + dist[MAXC];
     e.eff[1] = 1;
-    for (int i = 2; i <= 8; ++i) {
+    for (int i = 2; i <= MAXC; ++i) {
       if (dist[i] < e.c[i - 1]) { e.c[i] = dist[i]; e.eff[i] = (uint8_t)i; }
       else { e.c[i] = e.c[i - 1]; e.eff[i] = e.eff[i - 1]; }
     }
@@ -234,19 +263,19 @@ struct WideBuilder {
       dp_compute(ni);
       const DNode& n = bin[ni];
       const bool hl = SOL_REF_KIND(n.left) != SOL_REF_NONE, hr = SOL_REF_KIND(n.right) != SOL_REF_NONE;
-      if (hl && hr) { const int k = dp[ni].split[8]; dp_gather(n.left, lbox(n), k, c); dp_gather(n.right, rbox(n), 8 - k, c); }
+      if (hl && hr) { const int k = dp[ni].split[MAXC]; dp_gather(n.left, lbox(n), k, c); dp_gather(n.right, rbox(n), MAXC - k, c); }
       else { add(n.left, lbox(n)); add(n.right, rbox(n)); }
     } else {
     add(bin[ni].left, lbox(bin[ni]));
     add(bin[ni].right, rbox(bin[ni]));
-    while (c.size() < 8) {  // open the inner child with the largest surface until eight children (or only leaves) remain
+    while ((int)c.size() < MAXC) {  // open the inner child with the largest surface until MAXC children (or only leaves) remain
       int best = -1;
       float best_a = -1.f;
       for (size_t i = 0; i < c.size(); ++i)
         if (SOL_REF_KIND(c[i].ref) == SOL_REF_NODE) {
           const DNode& n = bin[SOL_REF_INDEX(c[i].ref)];
           int kids = (SOL_REF_KIND(n.left) != SOL_REF_NONE) + (SOL_REF_KIND(n.right) != SOL_REF_NONE);
-          if (c.size() - 1 + kids > 8) continue;
+          if ((int)c.size() - 1 + kids > MAXC) continue;
           float a = area(c[i].box);
           if (a > best_a) { best_a = a; best = (int)i; }
         }
@@ -258,7 +287,7 @@ struct WideBuilder {
     }
     }
     const uint32_t wi = (uint32_t)out.size();
-    out.push_back(DWide{});
+    out.push_back(XWide{});
     if (depth + 1 > max_depth) max_depth = depth + 1;
     for (auto& ch : c) (SOL_REF_KIND(ch.ref) == SOL_REF_NODE ? inner_area : leaf_area) += (double)area(ch.box);
     // node box and quantisation grid
@@ -279,6 +308,8 @@ struct WideBuilder {
         std::frexp(ext / 255.0f, &ex);  // ext/255 = m * 2^ex, m in [0.5,1)  ->  2^ex >= ext/255
         e = std::min(254, std::max(1, ex + 127));
       }
+      if (e > (int)emin + 31) range_error = true;  // (a box larger than the root's: cannot happen)
+      e = std::max((int)emin, std::min((int)emin + 31, e));
       eb[a] = (uint32_t)e;
       uint32_t bits = eb[a] << 23;
       std::memcpy(&scale[a], &bits, 4);
@@ -291,7 +322,7 @@ struct WideBuilder {
       // The device visits the hit children in the order slot ^ ray_octant, i.e. slot s is "far" along direction
       // (+-1, +-1, +-1)_s. Give child i slot s so that the summed projections of the child centres on their slots'
       // directions is largest (an 8x8 assignment problem, solved exactly: Kuhn-Munkres with potentials).
-      const int n = (int)c.size(), m = 8;
+      const int n = (int)c.size(), m = MAXC;
       double cost[9][9];
       for (int i = 1; i <= n; ++i) {
         const Box& b = c[i - 1].box;
@@ -338,7 +369,7 @@ struct WideBuilder {
         int pref = ((0.5f * (b.v[0] + b.v[1]) > ctr[0]) ? 4 : 0) | ((0.5f * (b.v[2] + b.v[3]) > ctr[1]) ? 2 : 0) |
                    ((0.5f * (b.v[4] + b.v[5]) > ctr[2]) ? 1 : 0);
         int best = -1, best_d = 99;
-        for (int s = 0; s < 8; ++s)
+        for (int s = 0; s < MAXC; ++s)
           if (!used[s]) {
             int d = __builtin_popcount((unsigned)(s ^ pref));
             if (d < best_d) { best_d = d; best = s; }
@@ -378,13 +409,127 @@ struct WideBuilder {
       if (SOL_REF_KIND(r) == SOL_REF_NODE) r = build(SOL_REF_INDEX(r), depth + 1);
       refs[s] = r;
     }
-    DWide& w = out[wi];
-    w.ox = lo[0]; w.oy = lo[1]; w.oz = lo[2];
-    w.meta = eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)c.size() << 24);
+    XWide& w = out[wi];
+    for (int a = 0; a < 3; ++a) { w.o[a] = lo[a]; w.e[a] = eb[a]; }
     for (int k = 0; k < 12; ++k) w.q[k] = q[k];
     for (int k = 0; k < 8; ++k) w.ref[k] = refs[k];
     return SOL_MAKE_REF(SOL_REF_WIDE, wi);
   }
+  // A world that is one primitive: a root with that single child (the device always starts at a wide node).
+  uint32_t build_single(uint32_t prim_ref, const Box& box) {
+    std::vector<DNode> one(1);
+    DNode& n = one[0];
+    n.lxmin = box.v[0]; n.lxmax = box.v[1]; n.lymin = box.v[2]; n.lymax = box.v[3]; n.lzmin = box.v[4]; n.lzmax = box.v[5];
+    const Box e = empty_box();
+    n.rxmin = e.v[0]; n.rxmax = e.v[1]; n.rymin = e.v[2]; n.rymax = e.v[3]; n.rzmin = e.v[4]; n.rzmax = e.v[5];
+    n.left = prim_ref; n.right = SOL_MAKE_REF(SOL_REF_NONE, 0); n.pad0 = n.pad1 = 0;
+    single_ = one;
+    WideBuilder tmp(single_, pad);
+    tmp.emin = emin;
+    tmp.dp_collapse = false;
+    const uint32_t r = tmp.build(0, 0);
+    out = tmp.out; max_depth = tmp.max_depth; inner_area = tmp.inner_area; leaf_area = tmp.leaf_area; range_error = tmp.range_error;
+    return r;
+  }
+  std::vector<DNode> single_;
+};
+
+// Device form of the wide tree. Depth-first: a node's inner children get consecutive node indices (in slot order), the
+// primitives of a node whose leaves are all triangles (or all spheres, or all quads) get consecutive NEW indices in their
+// array; other nodes list full references (with new indices) in `leaf_refs`. new_of_old / old_of_new are the permutations of
+// the triangle / sphere / quad arrays (index 0 / 1 / 2); primitives the world tree does not hold keep their relative order
+// behind the others. remap() rewrites any primitive reference of the flattened scene (binary nodes, lights, mediums).
+struct WideLayout {
+  std::vector<DWide> nodes;
+  std::vector<uint32_t> leaf_refs;
+  std::vector<uint32_t> new_of_old[3], old_of_new[3];
+  uint32_t depth = 0;
+  std::string error;
+  static int arr(uint32_t kind) { return kind == SOL_REF_TRIANGLE ? 0 : kind == SOL_REF_SPHERE ? 1 : kind == SOL_REF_QUAD ? 2 : -1; }
+  uint32_t remap(uint32_t ref) const {
+    const int a = arr(SOL_REF_KIND(ref));
+    if (a < 0 || SOL_REF_INDEX(ref) >= new_of_old[a].size()) return ref;
+    return SOL_MAKE_REF(SOL_REF_KIND(ref), new_of_old[a][SOL_REF_INDEX(ref)]);
+  }
+  uint32_t take(uint32_t ref) {  // new index of primitive `ref`, assigned on first use
+    const int a = arr(SOL_REF_KIND(ref));
+    uint32_t& n = new_of_old[a][SOL_REF_INDEX(ref)];
+    if (n == 0xFFFFFFFFu) { n = (uint32_t)old_of_new[a].size(); old_of_new[a].push_back(SOL_REF_INDEX(ref)); }
+    return n;
+  }
+  bool run(const std::vector<XWide>& x, uint32_t root, uint32_t emin, uint32_t n_tris, uint32_t n_spheres, uint32_t n_quads) {
+    const uint32_t counts[3] = {n_tris, n_spheres, n_quads};
+    for (int a = 0; a < 3; ++a) { new_of_old[a].assign(counts[a], 0xFFFFFFFFu); old_of_new[a].clear(); old_of_new[a].reserve(counts[a]); }
+    nodes.assign(1, DWide{});
+    leaf_refs.clear();
+    struct Item { uint32_t xi, ni, depth; };
+    std::vector<Item> stk{{root, 0u, 1u}};
+    while (!stk.empty()) {
+      const Item it = stk.back();
+      stk.pop_back();
+      if (it.depth > depth) depth = it.depth;
+      const XWide& w = x[it.xi];
+      uint32_t imask = 0, lmask = 0, n_inner = 0, n_leaf = 0, kind0 = SOL_REF_NONE;
+      bool direct = true;
+      for (int s = 0; s < SOL_WIDE_CHILDREN; ++s) {
+        const uint32_t k = SOL_REF_KIND(w.ref[s]);
+        if (k == SOL_REF_NONE) continue;
+        if (k == SOL_REF_WIDE) { imask |= 1u << s; n_inner++; continue; }
+        lmask |= 1u << s;
+        n_leaf++;
+        const int a = arr(k);
+        if (a < 0) { direct = false; continue; }  // a constant medium: always listed by reference
+        if (SOL_REF_INDEX(w.ref[s]) >= counts[a]) { error = "primitive reference out of range"; return false; }
+        if (kind0 == SOL_REF_NONE) kind0 = k; else if (k != kind0) direct = false;
+        if (new_of_old[a][SOL_REF_INDEX(w.ref[s])] != 0xFFFFFFFFu) direct = false;  // (shared sub-tree: already placed elsewhere)
+      }
+      if (SOL_REF_KIND(w.ref[7]) != SOL_REF_NONE) { error = "slot 7 of a wide node is in use"; return false; }
+      const uint32_t base_inner = (uint32_t)nodes.size();
+      uint32_t base_prim = 0, leaf_kind = SOL_LEAF_REFS;
+      if (n_leaf) {
+        if (direct && kind0 != SOL_REF_NONE) {
+          leaf_kind = kind0 == SOL_REF_TRIANGLE ? SOL_LEAF_TRIANGLES : kind0 == SOL_REF_SPHERE ? SOL_LEAF_SPHERES : SOL_LEAF_QUADS;
+          base_prim = (uint32_t)old_of_new[arr(kind0)].size();
+          for (int s = 0; s < SOL_WIDE_CHILDREN; ++s)
+            if (lmask & (1u << s)) take(w.ref[s]);  // consecutive: nothing else allocates in between
+        } else {
+          base_prim = (uint32_t)leaf_refs.size();
+          for (int s = 0; s < SOL_WIDE_CHILDREN; ++s)
+            if (lmask & (1u << s)) {
+              const uint32_t r = w.ref[s];
+              leaf_refs.push_back(arr(SOL_REF_KIND(r)) >= 0 ? SOL_MAKE_REF(SOL_REF_KIND(r), take(r)) : r);
+            }
+        }
+      }
+      if ((uint64_t)base_inner + n_inner > SOL_WIDE_MAX_INDEX || (uint64_t)base_prim + n_leaf > SOL_WIDE_MAX_INDEX) {
+        error = "more than 2^24 wide nodes or primitives of one kind";
+        return false;
+      }
+      nodes.resize(nodes.size() + n_inner);
+      DWide& o = nodes[it.ni];
+      o.ox = w.o[0]; o.oy = w.o[1]; o.oz = w.o[2];
+      for (int a = 0; a < 3; ++a)
+        if (w.e[a] < emin || w.e[a] > emin + 31) { error = "wide-node exponent outside the 5-bit range"; return false; }
+      o.meta = (w.e[0] - emin) | ((w.e[1] - emin) << 5) | ((w.e[2] - emin) << 10) | (imask << 15) | (lmask << 22) | (leaf_kind << 29);
+      for (int k = 0; k < 12; ++k) o.q[k] = w.q[k];
+      const uint32_t bi = n_inner ? base_inner : 0u;
+      for (int k = 0; k < 3; ++k) {  // slot-7 bytes: top byte of the second word of each plane array
+        o.q[2 * k + 1] = (o.q[2 * k + 1] & 0x00FFFFFFu) | (((bi >> (8 * k)) & 0xFFu) << 24);
+        o.q[6 + 2 * k + 1] = (o.q[6 + 2 * k + 1] & 0x00FFFFFFu) | (((base_prim >> (8 * k)) & 0xFFu) << 24);
+      }
+      // children in reverse slot order onto the stack: the first child's sub-tree is laid out right behind the sibling block
+      uint32_t rank = n_inner;
+      for (int s = SOL_WIDE_CHILDREN - 1; s >= 0; --s)
+        if (imask & (1u << s)) { --rank; stk.push_back(Item{SOL_REF_INDEX(w.ref[s]), base_inner + rank, it.depth + 1}); }
+    }
+    for (int a = 0; a < 3; ++a)  // primitives outside the world tree (e.g. the quads of a medium boundary) follow in their old order
+      for (uint32_t i = 0; i < counts[a]; ++i)
+        if (new_of_old[a][i] == 0xFFFFFFFFu) { new_of_old[a][i] = (uint32_t)old_of_new[a].size(); old_of_new[a].push_back(i); }
+    return true;
+  }
+  // decode helpers shared with sol_world_tree_check
+  static uint32_t base_inner(const DWide& w) { return (w.q[1] >> 24) | ((w.q[3] >> 24) << 8) | ((w.q[5] >> 24) << 16); }
+  static uint32_t base_prim(const DWide& w) { return (w.q[7] >> 24) | ((w.q[9] >> 24) << 8) | ((w.q[11] >> 24) << 16); }
 };
 
 // Rebuilds the WORLD's binary tree over the same primitives with a binned surface-area heuristic. The closest hit of a

@@ -34,26 +34,39 @@ struct __attribute__((aligned(16))) DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode");
 
-// 96-byte 8-wide node with 8-bit quantised child boxes, built at upload from the binary tree (sol_api.cpp, WideBuilder).
-// One visit costs 6 dwordx4 accesses per lane for 8 children, against 4 per 2 children for DNode: a third of the dependent
-// memory round trips per ray (the binary-tree kernel was bound by the CU's divergent lane-access rate, TA/TD busy 80-99 %)
-// and fewer steps for the per-step costs of a divergent wave (narrower collapses were measured: 13.0 node visits per ray
-// on C3 at width 8, 14.9 at 6, 18.1 at 4, 34.5 at 2; each narrower tree is slower end to end). Child i's box is
-//   lo = origin + q_lo[i] * scale,  hi = origin + q_hi[i] * scale,  scale_axis = 2^(e_axis - 127)
-// and CONTAINS the child's padded fp32 box (the builder checks the decoded values), so it is a pure cull: results do not
-// depend on it. Children sit in the slot whose index bits (x<<2 | y<<1 | z) match their octant of the node, so that
-// visiting slots in the order (k ^ ray_octant) is roughly front to back.
+// 64-byte 7-wide node with 8-bit quantised child boxes and IMPLICIT child addresses, built at upload from a binary tree
+// (sol_tree.h: WideBuilder + WideLayout). Half a 128-byte cache line, never straddling one: a visit costs 4 dwordx4 accesses per
+// lane and at most one line fill. Why so small: the render kernel's time follows its vector-memory work 1:1 (measured with
+// probe builds) - every lane visits another node, each 16-byte access is its own L1 look-up (~0.55 clk/lane on
+// MI355X, tests/tools/micro/l1_gather.hip), and the first touch of a node is an L2 fill of its whole line. The first layout
+// (96 B: the same boxes plus eight explicit 32-bit child references, 6 accesses, half of the nodes straddling two lines) took
+// 1.5x the accesses; padding it to 128 B to avoid the straddling was 4 % SLOWER (footprint, L2 hit rate). Narrower trees were
+// measured earlier with explicit references: 13.0 node visits per ray on C3 at width 8, 14.9 at 6, 18.1 at 4, 34.5 at 2.
+//   child i of a node sits in SLOT s(i) in 0..6 (slot 7 does not exist: its byte in each of the six plane arrays carries the
+//   two base indices). Slots are octants of the node (x<<2 | y<<1 | z), so that visiting slots in the order (s ^ ray_octant)
+//   is front to back. Child box: lo = origin + q_lo[s] * scale, hi = origin + q_hi[s] * scale, scale_axis = 2^(e_axis +
+//   DevScene::wide_emin - 127); it CONTAINS the child's padded fp32 box (the builder checks the decoded values): a pure cull.
+//   imask bit s: slot s holds an inner node, namely node  base_inner + popcount(imask & ((1 << s) - 1));
+//   lmask bit s: slot s holds a primitive, number          base_prim + popcount(lmask & ((1 << s) - 1))  of
+//     kind 1: the triangle array, 2: the sphere array, 3: the quad array (the arrays are permuted at upload so that the
+//     primitives of a node are consecutive), 0: DevScene::leaf_refs (full references; nodes with mixed kinds or a medium).
 #define SOL_REF_WIDE 6u  // device-only reference kind
 #ifndef SOL_WORLD_BINARY
 #define SOL_WORLD_BINARY false  // -DSOL_WORLD_BINARY=true: A/B variant that walks the 2-wide tree for the world as well
 #endif
-struct __attribute__((aligned(16))) DWide {
+#define SOL_WIDE_CHILDREN 7
+#define SOL_WIDE_MAX_INDEX 0x00FFFFFFu  // 24-bit base indices
+struct __attribute__((aligned(64))) DWide {
   float ox, oy, oz;
-  uint32_t meta;      // ex | ey << 8 | ez << 16 (biased exponents of the scales) | child count << 24
-  uint32_t q[12];     // q_lo_x[8], q_lo_y[8], q_lo_z[8], q_hi_x[8], q_hi_y[8], q_hi_z[8]: one byte per child slot
-  uint32_t ref[8];    // child references (SOL_REF_NONE for an empty slot)
+  uint32_t meta;      // ex | ey << 5 | ez << 10 (exponents - wide_emin) | imask << 15 | lmask << 22 | leaf kind << 29
+  uint32_t q[12];     // q_lo_x[8], q_lo_y[8], q_lo_z[8], q_hi_x[8], q_hi_y[8], q_hi_z[8]: one byte per slot; byte 7 of the three
+                      // lo arrays = base_inner (bits 0-7, 8-15, 16-23), of the three hi arrays = base_prim
 };
-static_assert(sizeof(DWide) == 96, "DWide");
+static_assert(sizeof(DWide) == 64, "DWide");
+#define SOL_LEAF_REFS 0u
+#define SOL_LEAF_TRIANGLES 1u
+#define SOL_LEAF_SPHERES 2u
+#define SOL_LEAF_QUADS 3u
 
 // 48-byte triangle intersect record (src/hittable/triangle.rs:14-17 v0, v0v1, v0v2)
 struct __attribute__((aligned(16))) DTri {
@@ -62,13 +75,15 @@ struct __attribute__((aligned(16))) DTri {
   float e2z;
   uint32_t dfs;
   int32_t mat;
-  uint32_t pad;
+  float area;         // (triangle.rs:27; read only by the light pdf of a triangle light)
 };
 static_assert(sizeof(DTri) == 48, "DTri");
 
-// 64-byte triangle shading record (triangle.rs:18-27 uv0..2, normal, tangent, bi_tangent, area)
+// 64-byte triangle shading record (triangle.rs:18-27 uv0..2, normal, tangent, bi_tangent) + the material index, so that shading
+// a hit touches this one record (half a cache line) and not the intersect record again
 struct __attribute__((aligned(16))) DTriShade {
-  float nx, ny, nz, area;
+  float nx, ny, nz;
+  int32_t mat;
   float tx, ty, tz, u0;
   float bx, by, bz, v0;
   float u1, v1, u2, v2;
@@ -133,8 +148,10 @@ struct DCamera {
 
 struct DevScene {
   const DNode* nodes;
-  const DWide* wides;   // 8-wide tree of the world (searches with t >= 0); binary nodes remain for medium boundaries
-  uint32_t wroot;       // reference of the world in the wide tree (kind SOL_REF_WIDE, or a primitive)
+  const DWide* wides;   // 7-wide tree of the world (searches with t >= 0); binary nodes remain for medium boundaries
+  const uint32_t* leaf_refs;  // references of the primitives of wide nodes with leaf kind 0
+  uint32_t wroot;       // index of the world's root in `wides`
+  uint32_t wide_emin;   // biased exponent that a DWide exponent field of 0 stands for
   const DTri* tris;
   const DTriShade* tri_shade;
   const DQuad* quads;

@@ -171,8 +171,8 @@ sol_wf_trace_kernel(const DevScene S, const RenderParams P, WfCounters* __restri
   const uint32_t lane = tid & 63u;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   Stack st;
-  st.lds = lds_stack + tid;
-  st.spill = spill + (blockIdx.x * SOL_WG + tid);
+  st.lds = (lds_u32*)lds_stack + tid;
+  st.spill = (SOL_AS1 uint32_t*)spill + (blockIdx.x * SOL_WG + tid);
   st.stride = P.total_threads;
   st.depth = SOL_LDS_STACK_TRACE;
   const size_t NS = P.pool_slots;
@@ -227,7 +227,7 @@ sol_wf_trace_kernel(const DevScene S, const RenderParams P, WfCounters* __restri
             rng_medium.k0 = __float_as_uint(r2.w); rng_medium.k1 = __float_as_uint(r3.w);
             depth_medium = __float_as_uint(r1.w) >> 8;
           }
-          trav_begin(t, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), RAY_MIN_F, inf, SOL_WORLD_ROOT(S), S.rxmin, S.rxmax, S.rymin, S.rymax,
+          trav_begin<!SOL_WORLD_BINARY>(t, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), RAY_MIN_F, inf, SOL_WORLD_ROOT(S), S.rxmin, S.rxmax, S.rymin, S.rymax,
                      S.rzmin, S.rzmax, 0);
           have = true;
           need = false;

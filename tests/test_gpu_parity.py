@@ -240,18 +240,23 @@ def test_max_depth_zero_and_one():
         assert_parity(scenes.cornell_box(RenderConfig(64, 64, 8, PathTracingShader(md))), 8)
 
 
+def _sphere_chain(b, n=50):
+    m = b.Lambertian(b.SolidColor(.8, .8, .8))
+    ids = [b.Sphere((float(x), 0.3 * (x % 3), 0.), 0.45, m) for x in range(n)]
+    inner = b.Bvh(ids[:2])
+    for k in range(2, n):
+        inner = b.Bvh([inner, ids[k]]) if k % 2 else b.Bvh([ids[k], inner])
+    return inner
+
+
 @pytest.mark.parametrize("bvh", ["ref", "sah"])
-def test_deep_tree_uses_the_spill_stack(bvh, monkeypatch):
-    """A BVH nested 48 levels deep (Bvh::new([sphere, Bvh::new([sphere, ...])]), each nested Bvh inlined as a node) is deeper
-    than the 32-entry LDS stack: the overflow goes to the global spill area. SOL_BVH=ref makes the device walk the reference's
-    own topology (its default is a SAH rebuild of the world, which re-balances this chain)."""
+def test_deep_world_tree(bvh, monkeypatch):
+    """A BVH nested 48 levels deep (Bvh::new([sphere, Bvh::new([sphere, ...])]), each nested Bvh inlined as a node) as the world.
+    SOL_BVH=ref makes the device collapse the reference's own topology (its default is a SAH rebuild, which re-balances the
+    chain). The 7-wide search keeps one sibling group per level, so even this chain stays inside the LDS stack."""
     monkeypatch.setenv("SOL_BVH", bvh)
     b = SceneBuilder()
-    m = b.Lambertian(b.SolidColor(.8, .8, .8))
-    ids = [b.Sphere((float(x), 0.3 * (x % 3), 0.), 0.45, m) for x in range(50)]
-    inner = b.Bvh(ids[:2])
-    for k in range(2, 50):
-        inner = b.Bvh([inner, ids[k]]) if k % 2 else b.Bvh([ids[k], inner])
+    inner = _sphere_chain(b)
     light = b.Sphere((0., 1e4, 0.), 3e3, b.DiffuseLight(3, 3, 3))
     cam = CameraConfig(12., 0., (-30., 0.4, 0.3), (50., 0.3, 0.), (0, 1, 0))  # looks along the row: every level is entered
     sc = b.finish(b.Bvh([inner, light]), cam, (.1, .1, .1), RenderConfig(64, 64, 4))
@@ -263,8 +268,24 @@ def test_deep_tree_uses_the_spill_stack(bvh, monkeypatch):
     ref, _ = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F32)
     assert pu.compare(img, ref, 4)["bad_pixels"] == 0
     assert st["samples"] == 64 * 64 * 4 and st["rays"] >= st["samples"]
-    if bvh == "ref":
-        assert st["max_stack"] > 32, st  # the spill area was really used
+
+
+def test_deep_medium_boundary_uses_the_spill_stack():
+    """The same 48-level chain as the BOUNDARY of a ConstantMedium: boundary searches walk the reference-shaped 2-wide tree with
+    one stack entry per level, deeper than the 32-entry LDS stack - the overflow goes to the global spill area."""
+    b = SceneBuilder()
+    fog = b.ConstantMedium(_sphere_chain(b), 0.4, (.9, .9, .9))
+    floor_ = b.Quad((-10., -1., -10.), (80., 0., 0.), (0., 0., 20.), b.Lambertian(b.SolidColor(.5, .6, .5)))
+    light = b.Sphere((0., 1e4, 0.), 3e3, b.DiffuseLight(3, 3, 3))
+    cam = CameraConfig(12., 0., (-30., 0.4, 0.3), (50., 0.3, 0.), (0, 1, 0))
+    sc = b.finish(b.Bvh([fog, floor_, light]), cam, (.1, .1, .1), RenderConfig(64, 64, 4))
+    with DeviceScene(sc) as ds:
+        ds.render(0, 4, pu.SEED, counted=True)
+        img = ds.read()
+        st = ds.stats()
+    ref, _ = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F32)
+    assert pu.compare(img, ref, 4)["bad_pixels"] == 0
+    assert st["max_stack"] > 32, st  # the spill area was really used
 
 
 @pytest.mark.parametrize("seed", range(48))
