@@ -220,6 +220,55 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
     const float tx = fminf(fminf(tfx, tfy), fminf(tfz, cull_t));                                                        \
     hits |= (te <= tx) ? (1u << (i)) : 0u; /* an empty slot has an inverted box; at worst it yields a NONE ref (no-op) */ \
   }
+// The slab tests of one fetched 7-wide node (h = origin + meta, qa / qb / qc = the six plane arrays) for the ray of search `t`:
+// the search's new node group and primitive group.
+template <bool COUNT>
+DEV void wide_node_test(const DevScene& S, Trav& t, uint32_t oct, float4 h, uint4 qa, uint4 qb, uint4 qc) {
+  const bool sx = (oct & 4u) != 0u, sy = (oct & 2u) != 0u, sz = (oct & 1u) != 0u;
+  const uint32_t meta = __float_as_uint(h.w);
+  const float scx = __uint_as_float(((meta & 31u) + S.wide_emin) << 23), scy = __uint_as_float((((meta >> 5) & 31u) + S.wide_emin) << 23);
+  const float scz = __uint_as_float((((meta >> 10) & 31u) + S.wide_emin) << 23);
+#ifdef SOL_NO_TCULL
+  const float cull_t = __builtin_huge_valf();
+#else
+  const float cull_t = t.h.t;  // t >= tmin > 0 in a world search
+#endif
+  uint32_t hits = 0u;
+  // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
+  // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
+  // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
+  const float ivx = __builtin_amdgcn_fmed3f(t.inv.x, -1e30f, 1e30f), ivy = __builtin_amdgcn_fmed3f(t.inv.y, -1e30f, 1e30f);
+  const float ivz = __builtin_amdgcn_fmed3f(t.inv.z, -1e30f, 1e30f);
+  const float ax = (h.x - t.o.x) * ivx, bx = scx * ivx;
+  const float ay = (h.y - t.o.y) * ivy, by = scy * ivy;
+  const float az = (h.z - t.o.z) * ivz, bz = scz * ivz;
+  // q words: qa = {lo_x[0..3], lo_x[4..7], lo_y[0..3], lo_y[4..7]}, qb = {lo_z.., lo_z.., hi_x.., hi_x..},
+  //          qc = {hi_y.., hi_y.., hi_z.., hi_z..}; near = the plane the ray meets first on that axis
+  const uint32_t nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
+  const uint32_t ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
+  const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
+  SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+  SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+  SOL_WIDE_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+  SOL_WIDE_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+  SOL_WIDE_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+  SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+  SOL_WIDE_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+  const uint32_t imask = (meta >> 15) & 0x7Fu, lmask = (meta >> 22) & 0x7Fu;
+  // inner hits into visit order: bit p <- bit p ^ octant (three conditional butterfly stages)
+  uint32_t ih = hits & imask;
+  ih = (oct & 1u) ? (((ih & 0x55u) << 1) | ((ih >> 1) & 0x55u)) : ih;
+  ih = (oct & 2u) ? (((ih & 0x33u) << 2) | ((ih >> 2) & 0x33u)) : ih;
+  ih = (oct & 4u) ? (((ih & 0x0Fu) << 4) | (ih >> 4)) : ih;
+  // base indices ride in the slot-7 bytes of the six plane arrays (lo x, y, z: inner; hi x, y, z: primitives)
+  const uint32_t base_inner = (qa.y >> 24) | ((qa.w >> 24) << 8) | ((qb.y >> 24) << 16);
+  const uint32_t base_prim = (qb.w >> 24) | ((qc.y >> 24) << 8) | ((qc.w >> 24) << 16);
+  t.g0 = base_inner | (ih << 24);
+  t.g1 = imask;
+  t.pg = base_prim | ((hits & lmask) << 24);
+  t.aux = oct | ((meta >> 29) << 3) | (lmask << 5);
+}
+
 // Tests primitive `idx` of kind `kind` against the search's interval [tmin, best t] and keeps it when it is the better hit
 // (smaller t; among equal t the later one in depth-first leaf order, bvh.rs:172-178).
 template <bool COUNT, bool MEDIUM>
@@ -266,6 +315,85 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
   phase_tick<COUNT>(cnt, 0);
   if (!BINARY) {
     const uint32_t oct = t.aux & 7u;
+#if SOL_UNIFIED_STEP
+    // One fetch per step: a lane either visits a node (no pending primitives) or tests one pending triangle / sphere; both
+    // fetch up to 64 bytes into the same registers, so the wave waits for memory ONCE per step, not once for its node lanes and
+    // once more for its primitive lanes. Primitives found by this step's node tests wait for the next step (where they add to
+    // the lanes that make a primitive round worth its instructions); quads and listed references take the general path.
+    const bool prim0 = (t.pg >> 24) != 0u;
+    bool do_prims = true;
+#if SOL_PRIM_MIN > 1
+    {
+      const unsigned long long pm = __ballot(prim0), im = __ballot(!prim0);
+      do_prims = im == 0ull || (int)__popcll(pm) >= SOL_PRIM_MIN;  // (wave-uniform) postponed primitive tests, as below
+    }
+#endif
+    const bool act_node = !prim0, act_prim = prim0 && do_prims;
+    const uint4* addr = nullptr;
+    uint32_t pkind = SOL_REF_NONE, pidx = 0u;
+    if (act_node) {
+      uint32_t g0 = t.g0, g1 = t.g1;
+      if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
+        g1 = stack_pop(st, t.sp);
+        g0 = stack_pop(st, t.sp);
+      }
+      const uint32_t p = (uint32_t)__builtin_ctz(g0 >> 24);  // nearest: lowest bit in visit order
+      const uint32_t slot = p ^ oct;
+      g0 &= ~(1u << (24u + p));
+      const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc(g1 & ((1u << slot) - 1u));
+      if ((g0 >> 24) != 0u) {  // siblings left: one stack entry for all of them
+        stack_push(st, t.sp, g0);
+        stack_push(st, t.sp, g1);
+        if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
+      }
+      t.g0 = 0u;  // (overwritten by the node test below)
+      addr = reinterpret_cast<const uint4*>(S.wides + idx);
+      if (COUNT) cnt.node_visits++;
+    } else if (act_prim) {
+      const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
+      t.pg &= ~(1u << (24u + slot));
+      const uint32_t lmask = (t.aux >> 5) & 0x7Fu, lkind = (t.aux >> 3) & 3u;
+      pidx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(lmask & ((1u << slot) - 1u));
+      pkind = lkind == SOL_LEAF_TRIANGLES ? SOL_REF_TRIANGLE : lkind == SOL_LEAF_SPHERES ? SOL_REF_SPHERE : lkind == SOL_LEAF_QUADS ? SOL_REF_QUAD : SOL_REF_NONE;
+      if (pkind == SOL_REF_TRIANGLE) addr = reinterpret_cast<const uint4*>(S.tris + pidx);
+      else if (pkind == SOL_REF_SPHERE) addr = reinterpret_cast<const uint4*>(S.spheres + pidx);
+    }
+    if (addr != nullptr) {
+      const uint4 r0 = ldg_u4(addr), r1 = ldg_u4(addr + 1);
+      uint4 r2 = make_uint4(0u, 0u, 0u, 0u), r3 = make_uint4(0u, 0u, 0u, 0u);
+      if (pkind != SOL_REF_SPHERE) r2 = ldg_u4(addr + 2);
+      if (act_node) r3 = ldg_u4(addr + 3);
+      if (act_node) {
+        wide_node_test<COUNT>(S, t, oct, make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w)), r1, r2, r3);
+      } else if (pkind == SOL_REF_TRIANGLE) {
+        DTri T;
+        T.v0x = __uint_as_float(r0.x); T.v0y = __uint_as_float(r0.y); T.v0z = __uint_as_float(r0.z); T.e1x = __uint_as_float(r0.w);
+        T.e1y = __uint_as_float(r1.x); T.e1z = __uint_as_float(r1.y); T.e2x = __uint_as_float(r1.z); T.e2y = __uint_as_float(r1.w);
+        T.e2z = __uint_as_float(r2.x);
+        const uint32_t dfs = r2.y;
+        if (COUNT) cnt.triangle_tests++;
+        float tt, u, v;
+        if (tri_test(T, t.o, t.d, t.tmin, t.h.t, tt, u, v) && better(tt, dfs, t.h)) { t.h.t = tt; t.h.ref = SOL_MAKE_REF(SOL_REF_TRIANGLE, pidx); t.h.dfs = dfs; t.h.u = u; t.h.v = v; }
+      } else {
+        DSphere Sp;
+        Sp.cx = __uint_as_float(r0.x); Sp.cy = __uint_as_float(r0.y); Sp.cz = __uint_as_float(r0.z); Sp.radius = __uint_as_float(r0.w);
+        Sp.dfs = r1.x; Sp.mat = (int32_t)r1.y;
+        if (COUNT) cnt.sphere_tests++;
+        float tt;
+        if (sphere_test(Sp, t.o, t.d, t.tmin, t.h.t, S.sphere_slack, tt) && better(tt, Sp.dfs, t.h)) { t.h.t = tt; t.h.ref = SOL_MAKE_REF(SOL_REF_SPHERE, pidx); t.h.dfs = Sp.dfs; }
+      }
+    } else if (act_prim) {  // quads (80-byte records), listed references (a second, dependent fetch), mediums
+      uint32_t kind = pkind, idx = pidx;
+      if (pkind == SOL_REF_NONE) {
+        const uint32_t r = ldg_u32(S.leaf_refs + pidx);
+        kind = SOL_REF_KIND(r);
+        idx = SOL_REF_INDEX(r);
+      }
+      prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
+    }
+    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
+    return;
+#else
     if ((t.pg >> 24) == 0u) {
       uint32_t g0 = t.g0, g1 = t.g1;
       if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
@@ -281,7 +409,6 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
         stack_push(st, t.sp, g1);
         if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
       }
-      const bool sx = (oct & 4u) != 0u, sy = (oct & 2u) != 0u, sz = (oct & 1u) != 0u;
       const float4* wp = reinterpret_cast<const float4*>(S.wides + idx);
       const float4 h = ldg_f4(wp);
       const uint4 qa = ldg_u4(wp + 1), qb = ldg_u4(wp + 2), qc = ldg_u4(wp + 3);
@@ -309,48 +436,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
 #endif
       }
 #endif
-      const uint32_t meta = __float_as_uint(h.w);
-      const float scx = __uint_as_float(((meta & 31u) + S.wide_emin) << 23), scy = __uint_as_float((((meta >> 5) & 31u) + S.wide_emin) << 23);
-      const float scz = __uint_as_float((((meta >> 10) & 31u) + S.wide_emin) << 23);
-#ifdef SOL_NO_TCULL
-      const float cull_t = __builtin_huge_valf();
-#else
-      const float cull_t = t.h.t;  // t >= tmin > 0 in a world search
-#endif
-      uint32_t hits = 0u;
-      // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
-      // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
-      // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
-      const float ivx = __builtin_amdgcn_fmed3f(t.inv.x, -1e30f, 1e30f), ivy = __builtin_amdgcn_fmed3f(t.inv.y, -1e30f, 1e30f);
-      const float ivz = __builtin_amdgcn_fmed3f(t.inv.z, -1e30f, 1e30f);
-      const float ax = (h.x - t.o.x) * ivx, bx = scx * ivx;
-      const float ay = (h.y - t.o.y) * ivy, by = scy * ivy;
-      const float az = (h.z - t.o.z) * ivz, bz = scz * ivz;
-      // q words: qa = {lo_x[0..3], lo_x[4..7], lo_y[0..3], lo_y[4..7]}, qb = {lo_z.., lo_z.., hi_x.., hi_x..},
-      //          qc = {hi_y.., hi_y.., hi_z.., hi_z..}; near = the plane the ray meets first on that axis
-      const uint32_t nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
-      const uint32_t ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
-      const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
-      SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-      SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-      SOL_WIDE_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-      SOL_WIDE_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-      SOL_WIDE_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, 0)
-      SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, 0)
-      SOL_WIDE_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, 0)
-      const uint32_t imask = (meta >> 15) & 0x7Fu, lmask = (meta >> 22) & 0x7Fu;
-      // inner hits into visit order: bit p <- bit p ^ octant (three conditional butterfly stages)
-      uint32_t ih = hits & imask;
-      ih = (oct & 1u) ? (((ih & 0x55u) << 1) | ((ih >> 1) & 0x55u)) : ih;
-      ih = (oct & 2u) ? (((ih & 0x33u) << 2) | ((ih >> 2) & 0x33u)) : ih;
-      ih = (oct & 4u) ? (((ih & 0x0Fu) << 4) | (ih >> 4)) : ih;
-      // base indices ride in the slot-7 bytes of the six plane arrays (lo x, y, z: inner; hi x, y, z: primitives)
-      const uint32_t base_inner = (qa.y >> 24) | ((qa.w >> 24) << 8) | ((qb.y >> 24) << 16);
-      const uint32_t base_prim = (qb.w >> 24) | ((qc.y >> 24) << 8) | ((qc.w >> 24) << 16);
-      t.g0 = base_inner | (ih << 24);
-      t.g1 = imask;
-      t.pg = base_prim | ((hits & lmask) << 24);
-      t.aux = oct | ((meta >> 29) << 3) | (lmask << 5);
+      wide_node_test<COUNT>(S, t, oct, h, qa, qb, qc);
     }
     // status for the callers' loops, and for the postponing rule below
     const bool has_prim = (t.pg >> 24) != 0u;
@@ -379,6 +465,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
     if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
     return;
+#endif
   }
   uint32_t cur = t.cur;
   uint32_t kind = SOL_REF_KIND(cur);

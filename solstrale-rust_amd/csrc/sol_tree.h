@@ -195,7 +195,8 @@ struct WideBuilder {
   //   sub-trees near the leaves as wide nodes with two or three children: C3 has 92 075 nodes of 3.85 children on average
   //   under it and 51 567 of 6.09 under the DP; node visits per ray 12.9 -> 11.9 (C3), 9.8 -> 9.5 (C2), time -0.5 .. -3 %.
   bool dp_collapse = true;   // SOL_COLLAPSE=greedy selects the other rule (A/B)
-  static constexpr double NODE_COST = 2.5, PRIM_COST = 1.0;
+  double NODE_COST = std::getenv("SOL_NODE_COST") ? std::atof(std::getenv("SOL_NODE_COST")) : 2.5;  // (experiment knob)
+  static constexpr double PRIM_COST = 1.0;
   struct Dp { double c[9]; uint8_t eff[9], split[9]; bool done = false; };
   std::vector<Dp> dp;
   static Box unite(const Box& a, const Box& b) {
