@@ -198,12 +198,13 @@ void sol_scene_destroy(SolScene* scene);
 
 /* Creation options (no reference analogue: the reference has one BVH builder and no scheduler to tune). All-zero = the
  * defaults of sol_scene_create. The SOL_* environment variables of DESIGN.md 9 remain developer overrides, read once here. */
-#define SOL_TREE_AUTO 0    /* candidates on the host + counted probe renders on the device pick one (default)        */
+#define SOL_TREE_AUTO 0    /* the default: today the GPU build (SOL_TREE_DEVICE)                                      */
 #define SOL_TREE_REF 1     /* the reference's topology (src/hittable/bvh.rs:84-162), collapsed 8-wide                 */
 #define SOL_TREE_SAH8 2    /* host binned-SAH rebuild, 8 / 16 / 64 bins                                              */
 #define SOL_TREE_SAH16 3
 #define SOL_TREE_SAH64 4
-#define SOL_TREE_DEVICE 5  /* built on the GPU (LBVH + 8-wide collapse kernels, sol_build.hip)  */
+#define SOL_TREE_DEVICE 5  /* built on the GPU (Morton sort, PLOC clustering, 7-wide collapse: sol_build.hip; 8f rank 3) */
+#define SOL_TREE_HOST_PROBE 6 /* the four host candidates (1..4) + counted probe renders on the device pick one          */
 typedef struct SolCreateOptions {
   uint32_t size;            /* sizeof(SolCreateOptions): lets the struct grow                                         */
   int32_t world_tree;       /* SOL_TREE_*                                                                              */
@@ -317,8 +318,9 @@ int sol_gaussian_blur_weights(uint32_t kernel_size, double std_dev, double* out)
 
 int sol_stats(const SolScene* scene, SolStats* out);
 
-/* Diagnostic, host only (no device needed): builds the 8-wide quantised tree of the world exactly as sol_scene_create does
- * (use_sah = 0: collapsed from the reference's topology, 1: from the 16-bin SAH rebuild, n > 1: from the n-bin rebuild) and verifies its structure with the
+/* Diagnostic, host only (no device needed): builds the 7-wide quantised tree of the world exactly as sol_scene_create does
+ * (use_sah = 0: collapsed from the reference's topology, 1: from the 16-bin SAH rebuild, n > 1: from the n-bin rebuild; -1: the tree
+ * the GPU builder of SOL_TREE_DEVICE makes - this one needs a device) and verifies its structure with the
  * device's decode arithmetic. Returns SOL_OK with the findings in `out`; the tree is sound iff box_violations ==
  * leaf_mismatches == bad_empty_slots == 0. */
 typedef struct SolTreeCheck {
@@ -326,7 +328,7 @@ typedef struct SolTreeCheck {
   uint32_t n_leaf_refs;      /* primitive references reachable from the root                                      */
   uint32_t n_primitives;     /* primitive references of the reference-shaped tree (the multiset the tree must hold)*/
   uint32_t depth;            /* levels of wide nodes                                                              */
-  uint32_t max_children;     /* most children in one node (<= 8)                                                  */
+  uint32_t max_children;     /* most children in one node (<= 7)                                                  */
   uint32_t box_violations;   /* children whose decoded box does not contain every padded primitive box below it   */
   uint32_t leaf_mismatches;  /* primitive references missing from / surplus in the tree                           */
   uint32_t bad_empty_slots;  /* empty slots that are not (NONE reference, inverted box)                           */

@@ -17,9 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 BUILD = os.path.join(HERE, "_build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SRC = ["csrc/sol_render.hip", "csrc/sol_wavefront.hip", "csrc/sol_aux.hip", "csrc/sol_api.cpp"]
+HIP_SRC = ["csrc/sol_render.hip", "csrc/sol_wavefront.hip", "csrc/sol_aux.hip", "csrc/sol_build.hip", "csrc/sol_api.cpp"]
 HIP_HDR = ["csrc/sol_types.h", "csrc/sol_math.h", "csrc/sol_trace.h", "csrc/sol_shade.h", "csrc/sol_path.h", "csrc/sol_launch.h",
-           "csrc/sol_tree.h", "../include/solstrale_hip.h"]
+           "csrc/sol_tree.h", "csrc/sol_build.h", "../include/solstrale_hip.h"]
 HOST_SRC = ["host/solstrale_host.cpp", "host/solstrale_obj.cpp", "host/solstrale_host_c.cpp"]
 HOST_DEPS = HOST_SRC + ["host/solstrale.hpp", "../include/solstrale_hip.h", "../include/solstrale_host.h"]
 

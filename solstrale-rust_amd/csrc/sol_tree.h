@@ -155,7 +155,7 @@ struct WideBuilder {
   // coarser grid 2^emin (still containing, only less tight: 31 binary orders below the scene's size).
   uint32_t emin = 1;
   bool range_error = false;
-  void set_exponent_range(const Box& root_box) {
+  static uint32_t exponent_min(const Box& root_box, float pad) {
     float ext = 0.f;
     for (int a = 0; a < 3; ++a) {
       const float e = root_box.v[2 * a + 1] - root_box.v[2 * a];
@@ -164,8 +164,9 @@ struct WideBuilder {
     int ex = -126;
     if (ext > 0.f) std::frexp((ext + 8.f * pad) / 255.0f, &ex);
     const int emax = std::min(254, std::max(1, ex + 127 + 1));  // one order of headroom for the pads added per level
-    emin = (uint32_t)std::max(1, emax - 31);
+    return (uint32_t)std::max(1, emax - 31);
   }
+  void set_exponent_range(const Box& root_box) { emin = exponent_min(root_box, pad); }
   uint32_t max_depth = 0;
   // surface-area estimate of a random ray's work: summed box areas of the children that are wide nodes / primitives
   // (a child is visited with probability ~ its area / the root's area)
@@ -527,6 +528,22 @@ struct WideLayout {
       for (uint32_t i = 0; i < counts[a]; ++i)
         if (new_of_old[a][i] == 0xFFFFFFFFu) { new_of_old[a][i] = (uint32_t)old_of_new[a].size(); old_of_new[a].push_back(i); }
     return true;
+  }
+  // the device build (sol_build.hip) delivers nodes, leaf_refs and new_of_old: derive the inverse maps and check them
+  bool adopt_device(std::vector<DWide>&& n, std::vector<uint32_t>&& refs, std::vector<uint32_t> (&no)[3], uint32_t levels) {
+    nodes = std::move(n);
+    leaf_refs = std::move(refs);
+    depth = levels;
+    for (int a = 0; a < 3; ++a) {
+      new_of_old[a] = std::move(no[a]);
+      old_of_new[a].assign(new_of_old[a].size(), 0xFFFFFFFFu);
+      for (uint32_t i = 0; i < new_of_old[a].size(); ++i) {
+        const uint32_t k = new_of_old[a][i];
+        if (k >= old_of_new[a].size() || old_of_new[a][k] != 0xFFFFFFFFu) { error = "device tree: the primitive map is not a permutation"; return false; }
+        old_of_new[a][k] = i;
+      }
+    }
+    return !nodes.empty();
   }
   // decode helpers shared with sol_world_tree_check
   static uint32_t base_inner(const DWide& w) { return (w.q[1] >> 24) | ((w.q[3] >> 24) << 8) | ((w.q[5] >> 24) << 16); }

@@ -76,6 +76,26 @@ def test_tree_and_schedule_variants_are_bit_identical(env, monkeypatch):
         assert (got == want).all(), (name, env, int((got != want).sum()))
 
 
+def test_device_built_tree_renders_the_same_frames():
+    """SolCreateOptions.world_tree = SOL_TREE_DEVICE: the world tree built by the GPU kernels of sol_build.hip instead of the
+    host builders. Closest hits do not depend on the tree, so the frames must be bit-identical (reference rule the device
+    stays results-compatible with: src/hittable/bvh.rs:165-180 + src/util/interval.rs:67-69, the tie rule)."""
+    for make, cfg in ((scenes.cornell_box, RenderConfig(200, 200, 16)), (scenes.cornell_spheres, RenderConfig(480, 270, 16)),
+                      (scenes.sponza_like, RenderConfig(480, 270, 16)), (scenes.create_test_scene, RenderConfig(200, 100, 16)),
+                      (scenes.create_obj_scene, RenderConfig(200, 100, 8))):
+        sc = make(cfg)
+        with DeviceScene(sc, world_tree=_abi.TREE_HOST_PROBE) as ds:  # the four host candidates + probe
+            ds.render(0, cfg.samples_per_pixel, pu.SEED)
+            want = ds.read()
+            assert ds.build_times()["device_tree"] == 0
+        with DeviceScene(sc, world_tree=_abi.TREE_DEVICE) as ds:
+            ds.render(0, cfg.samples_per_pixel, pu.SEED)
+            got = ds.read()
+            bt = ds.build_times()
+        assert (got == want).all(), (make.__name__, int((got != want).sum()))
+        assert bt["device_tree"] > 0 and bt["probes"] < bt["device_tree"] + 1.0
+
+
 def test_heavy_first_work_order_changes_nothing(monkeypatch):
     """Scenes with long paths (glass) get their costly pixel blocks scheduled first (cost probe at scene creation,
     sol_path.h decode_item_ordered); the frame must be the one of the plain order, for one rank and for a partition."""

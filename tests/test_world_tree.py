@@ -84,3 +84,17 @@ def test_random_scenes_build_sound_trees(seed):
         r = world_tree_check(sc, use_sah)
         assert r["box_violations"] == 0 and r["leaf_mismatches"] == 0 and r["bad_empty_slots"] == 0, (seed, use_sah, r)
         assert r["n_leaf_refs"] == r["n_primitives"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(SCENES))
+def test_device_built_tree_is_sound(name):
+    """The tree sol_build.hip builds ON THE GPU (SolCreateOptions.world_tree = SOL_TREE_DEVICE: Morton sort, PLOC clustering,
+    surface-area collapse, per-level emission) under the same structural check: every primitive reference once, every decoded
+    child box containing the padded primitive boxes below it, valid permutations of the primitive arrays."""
+    sc = SCENES[name]()
+    r = world_tree_check(sc, -1)
+    assert r["box_violations"] == 0 and r["leaf_mismatches"] == 0 and r["bad_empty_slots"] == 0, r
+    assert r["n_leaf_refs"] == r["n_primitives"] >= 2
+    assert 1 <= r["max_children"] <= 7 and r["depth"] >= 1
+    assert r["n_wide"] <= max(1, (r["n_primitives"] + 1) // 2)
