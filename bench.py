@@ -78,6 +78,8 @@ def parse_args():
                                               "procedural stand-in; config.workload then names the file")
     ap.add_argument("--camera", default="", help="with --obj: fx,fy,fz,tx,ty,tz[,vfov] (look_from, look_at)")
     ap.add_argument("--light", default="", help="with --obj: qx,qy,qz,ux,uy,uz,vx,vy,vz[,r,g,b] Quad light (corner, two edges)")
+    ap.add_argument("--hdri", action="store_true", help="c5 only: add the procedural HDR environment map (EXTENSION: the reference has no "
+                                                        "environment lights; reported separately from the plain c5 line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic = null, no roofline_valu)")
@@ -149,6 +151,8 @@ def pmc_passes(args, spp):
             cmd = [rocprof, "--pmc"] + grp + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                                               os.path.abspath(__file__), "--workload", args.workload, "--spp", str(spp), "--steps", "1",
                                               "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-build"]
+            if args.hdri:
+                cmd += ["--hdri"]
             if args.obj:
                 cmd += ["--obj", args.obj] + (["--camera", args.camera] if args.camera else []) + (["--light", args.light] if args.light else [])
             try:
@@ -194,8 +198,9 @@ def make_scene(args, spp_total):
                 f"{scenes.SPONZA_TRIANGLES} triangles, 24 Lambertian materials (8 image-textured), 1 quad light + sky")
         make = lambda rc: scenes.sponza_like(rc)
     elif wl == "c5":
-        name = f"C5 statue-class displaced mesh (stand-in), ~{scenes.STATUE_TRIANGLES} triangles, Metal(0.1) + Dielectric(1.5), 1 quad light"
-        make = lambda rc: scenes.statue_like(rc)
+        name = (f"C5 statue-class displaced mesh (stand-in), ~{scenes.STATUE_TRIANGLES} triangles, Metal(0.1) + Dielectric(1.5), 1 quad light" +
+                (" + procedural 2048x1024 HDR environment map (EXTENSION: not in the reference)" if args.hdri else ""))
+        make = lambda rc: scenes.statue_like(rc, environment=args.hdri)
     elif wl == "c2":
         name = "C2 Cornell box + 10000 Lambertian spheres"
         make = lambda rc: scenes.cornell_spheres(rc)

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define SOL_ABI_VERSION 1
+#define SOL_ABI_VERSION 2  /* 2: SolSceneDesc ends with the optional environment map; a version-1 description (without those
+                           * fields) is still accepted */
 
 /* ---- error codes ---------------------------------------------------------------------------------- */
 #define SOL_OK 0
@@ -168,6 +169,14 @@ typedef struct SolSceneDesc {
   /* `Renderer.lights` = world.get_lights() in depth-first order (src/renderer/mod.rs:126,141;
    * src/hittable/bvh.rs:186-193): references to light primitives */
   const uint32_t* lights;       uint32_t n_lights;
+  /* ---- abi_version >= 2: EXTENSION, not in the reference (which only has the constant `background_color`,
+   * src/renderer/mod.rs:197-204; BASELINE.json config 5 names an "HDRI env light"). A latitude-longitude map of linear RGB
+   * radiance, fp32, row 0 = up (+y): a ray that hits nothing returns env_scale * texel(direction) instead of `background`.
+   * The direction is mapped like a point on the reference's unit sphere (calculate_sphere_uv, src/hittable/sphere.rs:134-140)
+   * and the texel picked like an ImageMap's (nearest, src/material/texture.rs:170-179). It is NOT importance-sampled: the
+   * scene still needs a light (Renderer::new). env_texels == NULL (or width/height 0) = no environment. */
+  const float* env_texels;      uint32_t env_width, env_height;
+  double env_scale;
 } SolSceneDesc;
 
 /* Counters of the last instrumented render (sol_render_counted); zero otherwise. Definitions are the

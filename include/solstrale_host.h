@@ -68,6 +68,9 @@ const SolSceneDesc* solh_finish(SolhBuilder* b, int world, uint32_t width, uint3
                                 double aperture_size, const double look_from[3], const double look_at[3],
                                 const double up[3]);
 /* deepest Bvh nesting of the flattened tree (information for the device stack) */
+/* EXTENSION, not in the reference: a latitude-longitude environment map (width * height * 3 floats, linear radiance, row 0 =
+ * up) that rays which hit nothing return, scaled, instead of Scene.background_color (SolSceneDesc.env_*). Before solh_finish. */
+int solh_environment(SolhBuilder* b, uint32_t width, uint32_t height, const float* rgb, double scale);
 uint32_t solh_tree_depth(const SolhBuilder* b);
 
 /* ray_trace (src/lib.rs:93-99) on the scene of the last solh_finish: samples_per_pixel passes, progress

@@ -227,6 +227,7 @@ template <typename R> struct Scene {
   std::vector<uint32_t> lights;
   uint32_t root = 0, width = 0, height = 0, shader = 0, max_depth = 0;
   V3<R> background;
+  const float* env = nullptr; uint32_t env_w = 0, env_h = 0; R env_scale = 1;  // EXTENSION (SolSceneDesc, abi_version >= 2)
   V3<R> cam_origin, cam_llc, cam_h, cam_v, cam_u, cam_vv; R lens_radius = 0;
   R box_pad = 0;  // fp32 box pad (0 in f64)
 
@@ -234,6 +235,7 @@ template <typename R> struct Scene {
   explicit Scene(const SolSceneDesc& d) {
     root = d.root; width = d.width; height = d.height; shader = d.shader_kind; max_depth = d.max_depth;
     background = cv(d.background);
+    if (d.abi_version >= 2 && d.env_texels && d.env_width && d.env_height) { env = d.env_texels; env_w = d.env_width; env_h = d.env_height; env_scale = (R)d.env_scale; }
     cam_origin = cv(d.camera.origin); cam_llc = cv(d.camera.lower_left_corner); cam_h = cv(d.camera.horizontal);
     cam_v = cv(d.camera.vertical); cam_u = cv(d.camera.u); cam_vv = cv(d.camera.v); lens_radius = (R)d.camera.lens_radius;
     // fp32 box contract: cast, then pad outward by S * 2^-20, S = largest finite |coordinate| of the world's
@@ -496,6 +498,23 @@ template <typename R> struct Tracer {
     return onb.normal;
   }
 
+  // EXTENSION, not in the reference (include/solstrale_hip.h, SolSceneDesc::env_*): radiance of a ray that hits nothing, from a
+  // latitude-longitude map. Direction -> (u, v) as a point of the reference's unit sphere (calculate_sphere_uv, sphere.rs:134-140),
+  // nearest texel, row 0 = up.
+  V3<R> env_color(const V3<R>& dir) {
+    const V3<R> n = dir.unit();
+    const R theta = acos_r(-n.y);
+    const R phi = -atan2_r(n.z, n.x) + Consts<R>::pi;
+    const float u = (float)(phi / ((R)2 * Consts<R>::pi)), v = (float)(theta / Consts<R>::pi);
+    const float x = u * ((float)sc.env_w - 1.f), y = (1.f - v) * ((float)sc.env_h - 1.f);
+    uint32_t xi = x >= 0.f ? (x < 4294967296.f ? (uint32_t)x : 0xFFFFFFFFu) : 0u;
+    uint32_t yi = y >= 0.f ? (y < 4294967296.f ? (uint32_t)y : 0xFFFFFFFFu) : 0u;
+    if (xi >= sc.env_w) xi = sc.env_w - 1;
+    if (yi >= sc.env_h) yi = sc.env_h - 1;
+    const float* p = sc.env + ((size_t)yi * sc.env_w + xi) * 3;
+    return V3<R>{(R)p[0], (R)p[1], (R)p[2]} * sc.env_scale;
+  }
+
   struct RayHit { V3<R> p, normal; int mat; R t; UvF uv; bool front; };
 
   // ---- light pdf (pdf.rs:75-102; quad.rs:132-148; triangle.rs:100-117; sphere.rs:40-62,142-153) ---------------
@@ -649,7 +668,7 @@ template <typename R> struct Tracer {
                              (float)ray.direction.z, any_hit ? (float)c.t : std::numeric_limits<float>::infinity(), rf, 0.f, (float)depth, 0.f, 0.f};
       trace->insert(trace->end(), row, row + 12);
     }
-    if (!any_hit) return {sc.background, false, 0, 0};  // renderer/mod.rs:197-204
+    if (!any_hit) return {sc.env ? env_color(ray.direction) : sc.background, false, 0, 0};  // renderer/mod.rs:197-204
     RayHit rec{c.p, {}, c.mat, c.t, c.uv, c.front};
     rec.normal = transformed_normal(c.mat, c.onb, c.uv);  // RayHit::new (material/mod.rs:50), closest hit only
     switch (sc.shader) {

@@ -87,7 +87,7 @@ struct SolScene {
   uint32_t* leaf_refs = nullptr;
   DNode* nodes = nullptr; DWide* wides = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
   DSphere* spheres = nullptr; DMedium* mediums = nullptr; DMat* mats = nullptr; DTex* texs = nullptr;
-  uint8_t* texels = nullptr; uint32_t* lights = nullptr;
+  uint8_t* texels = nullptr; uint32_t* lights = nullptr; float* env = nullptr;
   float* acc_own = nullptr; float* acc = nullptr; size_t acc_floats = 0;
   float* aux[2] = {nullptr, nullptr}; size_t aux_floats = 0;
   std::vector<uint32_t> block_cost;  // per 8x8 block (global index): rays of its longest item in the cost probe; empty: no ordering
@@ -342,7 +342,7 @@ void sol_scene_destroy(SolScene* s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   sol_comm_destroy(s);
-  void* ptrs[] = {s->leaf_refs, s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->lights,
+  void* ptrs[] = {s->leaf_refs, s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->env, s->lights,
                   s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters, s->pool, s->queue, s->wf_ctr,
                   s->bloom_a, s->bloom_b, s->bloom_w, s->aux[0], s->aux[1], s->dscene, s->order_dev};
   if (s->wf_ctr_host) hipHostFree(s->wf_ctr_host);
@@ -367,7 +367,9 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   if (opt.world_tree < SOL_TREE_AUTO || opt.world_tree > SOL_TREE_HOST_PROBE) return fail(SOL_EINVAL, "bad world_tree option %d", opt.world_tree);
   const auto t_begin = std::chrono::steady_clock::now();
   auto seconds_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-  if (d->abi_version != SOL_ABI_VERSION) return fail(SOL_EINVAL, "abi_version %u, expected %u", d->abi_version, SOL_ABI_VERSION);
+  if (d->abi_version != SOL_ABI_VERSION && d->abi_version != 1u) return fail(SOL_EINVAL, "abi_version %u, expected %u (or 1)", d->abi_version, SOL_ABI_VERSION);
+  const bool has_env = d->abi_version >= 2u && d->env_texels && d->env_width && d->env_height;  // (a version-1 description ends before these fields)
+  if (has_env && ((uint64_t)d->env_width * d->env_height > (1ull << 28) || !std::isfinite(d->env_scale))) return fail(SOL_EINVAL, "bad environment map");
   if (d->width < 2 || d->height < 2 || (uint64_t)d->width * d->height > 0x3FFFFFFFull) return fail(SOL_EINVAL, "bad image size %ux%u", d->width, d->height);
   if (d->shader_kind > SOL_SHADER_SIMPLE) return fail(SOL_EINVAL, "bad shader kind %u", d->shader_kind);
   if ((d->n_nodes && !d->nodes) || (d->n_spheres && !d->spheres) || (d->n_quads && !d->quads) ||
@@ -706,6 +708,12 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   S.rzmin = root_box.v[4]; S.rzmax = root_box.v[5];
   S.width = d->width; S.height = d->height; S.shader = d->shader_kind; S.max_depth = d->max_depth;
   S.sphere_slack = box_pad * 0.5f;
+  S.env = nullptr; S.env_w = S.env_h = 0; S.env_scale = 1.0f;
+  if (has_env) {
+    std::vector<float> env(d->env_texels, d->env_texels + (size_t)d->env_width * d->env_height * 3);
+    if ((rc = upload(env, &s->env))) return rc;
+    S.env = s->env; S.env_w = d->env_width; S.env_h = d->env_height; S.env_scale = (float)d->env_scale;
+  }
   S.bgx = (float)d->background[0]; S.bgy = (float)d->background[1]; S.bgz = (float)d->background[2];
   const SolCamera& c = d->camera;
   S.cam = DCamera{(float)c.origin[0], (float)c.origin[1], (float)c.origin[2],
@@ -1062,15 +1070,17 @@ int sol_render_aux(SolScene* s, uint32_t first, uint32_t n, uint64_t seed) {
   const uint32_t kinds[2] = {SOL_SHADER_ALBEDO, SOL_SHADER_NORMAL};
   int rc = SOL_OK;
   const float bg[3] = {s->S.bgx, s->S.bgy, s->S.bgz};
+  const float* const env = s->S.env;
   for (int k = 0; k < 2 && rc == SOL_OK; ++k) {
     s->acc = s->aux[k];
     s->S.shader = kinds[k];
-    if (k == 1) s->S.bgx = s->S.bgy = s->S.bgz = 0.0f;  // a miss: albedo = background colour, normal = ZERO_VECTOR (mod.rs:197-204)
+    if (k == 1) { s->S.bgx = s->S.bgy = s->S.bgz = 0.0f; s->S.env = nullptr; }  // a miss: albedo = background colour, normal = ZERO_VECTOR (mod.rs:197-204)
     rc = render_impl(s, first, n, seed, false);
   }
   s->acc = acc;
   s->S.shader = shader;
   s->S.bgx = bg[0]; s->S.bgy = bg[1]; s->S.bgz = bg[2];
+  s->S.env = env;
   return rc;
 }
 

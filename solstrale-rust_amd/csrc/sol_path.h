@@ -50,12 +50,29 @@ DEV void generate_path(const DevScene& S, uint32_t seed_lo, uint32_t seed_hi, ui
 
 DEV f3 ray_inverse(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }  // Ray::new (geo/mod.rs:277-285)
 
+// EXTENSION, not in the reference (include/solstrale_hip.h, SolSceneDesc::env_*): radiance of a ray that hits nothing, from a
+// latitude-longitude map; the arithmetic of oracle.cpp env_color in fp32.
+DEV f3 env_color(const DevScene& S, f3 dir) {
+  const f3 n = unit3(dir);
+  const float theta = acos_r(-n.y);
+  const float phi = -atan2_r(n.z, n.x) + SOL_PI;
+  const float u = phi / (2.0f * SOL_PI), v = theta / SOL_PI;
+  const float x = u * ((float)S.env_w - 1.0f), y = (1.0f - v) * ((float)S.env_h - 1.0f);
+  uint32_t xi = x >= 0.0f ? (x < 4294967296.0f ? (uint32_t)x : 0xFFFFFFFFu) : 0u;
+  uint32_t yi = y >= 0.0f ? (y < 4294967296.0f ? (uint32_t)y : 0xFFFFFFFFu) : 0u;
+  xi = min(xi, S.env_w - 1u);
+  yi = min(yi, S.env_h - 1u);
+  const float* p = S.env + ((size_t)yi * S.env_w + xi) * 3;
+  return mk3(__uint_as_float(ldg_u32(p)), __uint_as_float(ldg_u32(p + 1)), __uint_as_float(ldg_u32(p + 2))) * S.env_scale;
+}
+
 // Processes the result `h` of world.hit(ray) for the path `p`. Returns true when the sample is finished, with its colour
 // (get_attenuated_color applied) in `contrib`; returns false when the path continues with the new ray in p.o / p.d.
 template <bool COUNT>
 DEV bool shade_vertex(const DevScene& S, Path& p, const Hit& h, f3& contrib, Counters& cnt) {
   bool terminal = true;
   f3 x = mk3(S.bgx, S.bgy, S.bgz);  // miss: background (src/renderer/mod.rs:197-204)
+  if (S.env != nullptr && SOL_REF_KIND(h.ref) == SOL_REF_NONE) x = env_color(S, p.d);  // (extension: environment map)
   bool has_af = false;
   float af = 0.0f, path_len = 0.0f;
   if (SOL_REF_KIND(h.ref) != SOL_REF_NONE) {

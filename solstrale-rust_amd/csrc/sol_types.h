@@ -172,6 +172,9 @@ struct DevScene {
   uint32_t width, height, shader, max_depth;
   float sphere_slack;  // half the fp32 box pad: tolerance of the sphere hit-point-in-own-box rule (sol_trace.h)
   float bgx, bgy, bgz;
+  const float* env;      // EXTENSION (SolSceneDesc::env_*): latitude-longitude radiance map for rays that hit nothing; null = background
+  uint32_t env_w, env_h;
+  float env_scale;
   DCamera cam;
   // Work order of the one-path-per-lane kernel (sol_path.h, decode_item_ordered): block_order[k] = local block taken k-th, the
   // first n_first of them ("heavy": long paths, found by a counted probe at scene creation) with all their chunks up front;

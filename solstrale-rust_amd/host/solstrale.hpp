@@ -270,6 +270,10 @@ struct Scene {
   CameraConfig camera;
   Vec3 background_color;
   RenderConfig render_config;
+  // EXTENSION (not in the reference): latitude-longitude environment of linear radiance, row 0 = up; empty = none
+  std::vector<float> environment;
+  uint32_t env_width = 0, env_height = 0;
+  double env_scale = 1.0;
 };
 
 struct RenderProgress {

@@ -491,6 +491,8 @@ std::unique_ptr<FlatScene> flatten(const Scene& scene) {
   d.textures = fs->textures.data();     d.n_textures = (uint32_t)fs->textures.size();
   d.texels = fs->texels.data();         d.n_texel_bytes = fs->texels.size();
   d.lights = fs->lights.data();         d.n_lights = (uint32_t)fs->lights.size();
+  d.env_texels = scene.environment.empty() ? nullptr : scene.environment.data();  // (owned by the Scene, which outlives the FlatScene)
+  d.env_width = scene.env_width; d.env_height = scene.env_height; d.env_scale = scene.env_scale;
   return fs;
 }
 

@@ -233,6 +233,14 @@ const SolSceneDesc* solh_finish(SolhBuilder* b, int world, uint32_t width, uint3
     return nullptr;
   }
 }
+int solh_environment(SolhBuilder* b, uint32_t width, uint32_t height, const float* rgb, double scale) {
+  return guarded([&] {
+    if (!rgb || !width || !height) throw std::runtime_error("environment: empty map");
+    b->scene.environment.assign(rgb, rgb + (size_t)width * height * 3);
+    b->scene.env_width = width; b->scene.env_height = height; b->scene.env_scale = scale;
+    return 0;
+  });
+}
 uint32_t solh_tree_depth(const SolhBuilder* b) { return b->flat ? b->flat->max_depth_nodes : 0; }
 
 int solh_ray_trace(SolhBuilder* b, uint32_t spp, uint64_t seed, int strategy, double interval_seconds, int device,

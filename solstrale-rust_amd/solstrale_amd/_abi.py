@@ -13,7 +13,7 @@ BUILD_DIR = os.environ.get("SOLSTRALE_BUILD_DIR") or os.path.join(os.path.dirnam
 HIP_LIB = os.path.join(BUILD_DIR, "libsolstrale_hip.so")
 HOST_LIB = os.path.join(BUILD_DIR, "libsolstrale_host.so")
 
-SOL_ABI_VERSION = 1
+SOL_ABI_VERSION = 2
 SOL_OK, SOL_EINVAL, SOL_ENOLIGHT, SOL_EDEVICE, SOL_EDEPTH, SOL_ENOMEM = 0, -1, -2, -3, -4, -5
 REF_NONE, REF_NODE, REF_SPHERE, REF_QUAD, REF_TRIANGLE, REF_MEDIUM = range(6)
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC, MAT_BLEND = range(6)
@@ -88,7 +88,9 @@ class SolSceneDesc(C.Structure):
                 ("materials", C.POINTER(SolMaterial)), ("n_materials", C.c_uint32),
                 ("textures", C.POINTER(SolTexture)), ("n_textures", C.c_uint32),
                 ("texels", C.POINTER(C.c_uint8)), ("n_texel_bytes", C.c_uint64),
-                ("lights", C.POINTER(C.c_uint32)), ("n_lights", C.c_uint32)]
+                ("lights", C.POINTER(C.c_uint32)), ("n_lights", C.c_uint32),
+                ("env_texels", C.POINTER(C.c_float)), ("env_width", C.c_uint32), ("env_height", C.c_uint32),
+                ("env_scale", C.c_double)]
 
 
 class SolStats(C.Structure):
@@ -236,6 +238,7 @@ def load_host():
     _sig(lib, "solh_bvh_range", I, [B, I, I])
     _sig(lib, "solh_finish", C.POINTER(SolSceneDesc),
          [B, I, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _D3, D, D, _D3, _D3, _D3])
+    _sig(lib, "solh_environment", I, [B, C.c_uint32, C.c_uint32, C.c_void_p, D])
     _sig(lib, "solh_tree_depth", C.c_uint32, [B])
     _sig(lib, "solh_ray_trace", I, [B, C.c_uint32, C.c_uint64, I, D, I, PROGRESS_FN, ABORT_FN, C.c_void_p])
     _sig(lib, "solh_load_obj", I, [B, C.c_char_p, C.c_char_p, I, I, IMAGE_DECODER_FN, C.c_void_p])
@@ -250,7 +253,7 @@ HOST_SYMBOLS = ["solh_builder_new", "solh_builder_free", "solh_last_error", "sol
                 "solh_image_map", "solh_normal_texture", "solh_lambertian", "solh_metal", "solh_dielectric",
                 "solh_diffuse_light", "solh_blend", "solh_sphere", "solh_quad", "solh_box", "solh_triangle",
                 "solh_triangles", "solh_spheres", "solh_constant_medium", "solh_bvh", "solh_bvh_range", "solh_finish",
-                "solh_tree_depth", "solh_ray_trace", "solh_abi_sizes", "solh_to_rgb_color", "solh_set_post_processors", "solh_load_obj"]
+                "solh_tree_depth", "solh_environment", "solh_ray_trace", "solh_abi_sizes", "solh_to_rgb_color", "solh_set_post_processors", "solh_load_obj"]
 
 
 def d3(v):

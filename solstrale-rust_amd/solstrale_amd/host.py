@@ -277,6 +277,13 @@ class SceneBuilder:
     def Bvh_range(self, first, n):
         return self._chk(self.lib.solh_bvh_range(self.h, first, n))
 
+    def environment(self, rgb32f, scale=1.0):
+        """EXTENSION (not in the reference): a latitude-longitude map of linear radiance, (H, W, 3) float32, row 0 = up, that
+        rays which hit nothing return instead of the constant background colour. Call before finish()."""
+        a = np.ascontiguousarray(rgb32f, dtype=np.float32)
+        h, w, _ = a.shape
+        self._chk(self.lib.solh_environment(self.h, w, h, a.ctypes.data, float(scale)))
+
     def finish(self, world, camera, background_color, render_config):
         """`Scene{world, camera, background_color, render_config}` -> flattened description."""
         p = self.lib.solh_finish(self.h, world, render_config.width, render_config.height, render_config.shader[0],

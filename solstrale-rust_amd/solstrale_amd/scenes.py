@@ -274,10 +274,33 @@ def obj_file_scene(path, render_config=None, camera=None, light=None, background
     return b.finish(b.Bvh([model, lq]), cam, background, rc)
 
 
+def procedural_sky(width=2048, height=1024, sun_dir=(0.45, 0.7, -0.55), sun_radiance=60.0):
+    """A latitude-longitude HDR environment (H, W, 3) float32, row 0 = up, in the direction convention of SolSceneDesc::env_*
+    (the reference's sphere mapping, src/hittable/sphere.rs:134-140): horizon-to-zenith gradient, a darker ground half and a
+    small bright sun. Stand-in for the "HDRI env light" BASELINE.json's config 5 names (no HDR files offline)."""
+    v = (np.arange(height, dtype=np.float64) + 0.5) / height          # 0 = up .. 1 = down  (row = (1 - v_ref) * (h - 1))
+    u = (np.arange(width, dtype=np.float64) + 0.5) / width
+    theta = (1.0 - v) * np.pi                                          # v_ref = theta / pi, theta = acos(-y)
+    y = -np.cos(theta)[:, None]
+    phi = u * 2.0 * np.pi                                              # u = phi / 2pi, phi = -atan2(z, x) + pi
+    r = np.sqrt(np.maximum(0.0, 1.0 - y * y))
+    x = r * np.cos(np.pi - phi)[None, :]
+    z = r * np.sin(np.pi - phi)[None, :]
+    up = np.clip(y, 0.0, 1.0)
+    sky = np.stack([0.45 - 0.30 * up, 0.60 - 0.25 * up, 0.85 - 0.10 * up], -1) * np.ones((1, width, 1))
+    ground = np.array([0.10, 0.09, 0.08])
+    img = np.where((y > 0.0)[..., None] * np.ones((1, width, 1), bool), sky, ground)
+    sd = np.asarray(sun_dir, np.float64)
+    sd = sd / np.linalg.norm(sd)
+    cosang = x * sd[0] + y * sd[1] + z * sd[2]
+    img = img + (cosang > np.cos(np.radians(2.5)))[..., None] * sun_radiance
+    return img.astype(np.float32)
+
+
 STATUE_TRIANGLES = 1_090_000
 
 
-def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES):
+def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES, environment=False):
     """C5 stand-in: a procedurally displaced "statue" of about 1.09 M triangles - a noise-displaced body of
     Metal(fuzz 0.1), a Dielectric(1.5) head and a glass orb, a Lambertian plinth and drapery - on a floor quad under one
     quad light, constant background. (The Happy Buddha mesh and an HDRI light are not available / not in the reference.)"""
@@ -329,15 +352,19 @@ def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES):
     floor = b.Quad((-12., 0., -12.), (24., 0, 0), (0, 0, 24.), b.Lambertian(b.SolidColor(.4, .42, .45)))
     light = b.Quad((-2.5, 8.5, -1.0), (5., 0, 0), (0, 0, 4.), b.DiffuseLight(20., 19., 17.))
     cam = CameraConfig(vertical_fov_degrees=38., aperture_size=0., look_from=(4.5, 3.6, 8.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
+    if environment:  # EXTENSION (not in the reference): the "HDRI env light" of BASELINE.json's config 5, as a procedural HDR sky
+        b.environment(procedural_sky(), 1.0)
     return b.finish(b.Bvh([model, orb, floor, light]), cam, (0.25, 0.3, 0.4), rc)
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # The reference's test scenes (tests/scenes.rs)
 # ---------------------------------------------------------------------------------------------------------------
-def create_test_scene(render_config):
-    """tests/scenes.rs:17-122"""
+def create_test_scene(render_config, environment=None):
+    """tests/scenes.rs:17-122 (environment = (map, scale): the extension of create_test_scene_with_environment)"""
     b = SceneBuilder()
+    if environment is not None:
+        b.environment(*environment)
     cam = CameraConfig(20., 0.1, (-5., 3., 6.), (.25, 1., 0.), (0., 1., 0.))
     ground = b.Lambertian(b.ImageMap(load_image("textures/tex.jpg")))
     glass = b.Dielectric(b.SolidColor(1., 1., 1.), None, 1.5)
@@ -363,6 +390,11 @@ def create_test_scene(render_config):
     world.append(b.Quad((0., 0., 0.), (2., 0., 0.), (0., 0., 2.), light, [RotationY(45.), Translation((-1., 10., -1.))]))
     world.append(b.Triangle((-2., 1., -3.), (0., 1., -3.), (-1., 2., -3.), light))
     return b.finish(b.Bvh(world), cam, (.2, .3, .5), render_config)
+
+
+def create_test_scene_with_environment(render_config, size=(256, 128)):
+    """The reference's test scene under an environment map (EXTENSION, SolSceneDesc::env_*) instead of its constant background."""
+    return create_test_scene(render_config, environment=(procedural_sky(size[0], size[1]), 0.8))
 
 
 def create_simple_test_scene(render_config, add_light):
