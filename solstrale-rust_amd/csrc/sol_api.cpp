@@ -1007,7 +1007,7 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
       s->dscene_valid = true;
     }
     HIP_TRY(sol_launch_render(version, s->S, s->dscene, P, s->acc, s->partial, s->work, s->spill, s->pool, s->counters, grid, count,
-                              s->has_medium, s->stream));
+                              s->has_medium, s->tree_depth > (uint32_t)SOL_LDS_STACK, s->stream));
   }
   if (s->timing) { HIP_TRY(hipEventRecord(s->ev_stop, s->stream)); s->timed_launches++; }
   s->last_grid = grid;

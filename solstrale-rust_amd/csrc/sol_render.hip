@@ -24,7 +24,9 @@
 // ---------------------------------------------------------------------------------------------------------------------------
 // v1: one path per lane
 // ---------------------------------------------------------------------------------------------------------------------------
-template <bool COUNT, bool MEDIUM>
+// SPILL = false: built for scenes whose searches fit the LDS stack (sol_api.cpp picks it by the tree's depth): every stack access
+// is a plain LDS access, the spill branches and their waits fold away.
+template <bool COUNT, bool MEDIUM, bool SPILL>
 __global__ void __launch_bounds__(SOL_WG, SOL_V1_MIN_WAVES)  // 4 waves per SIMD: the 32 KiB LDS stack allows 5 workgroups per CU, 128 VGPRs 4
 sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* __restrict__ acc, float* __restrict__ partial,
                   uint32_t* __restrict__ work_counter, uint32_t* __restrict__ spill, DevCounters* __restrict__ dcnt) {
@@ -40,7 +42,8 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
   st.lds = (lds_u32*)lds_stack + tid;
   st.spill = (SOL_AS1 uint32_t*)spill + gtid;
   st.stride = P.total_threads;
-  st.depth = SOL_LDS_STACK;
+  st.depth = SPILL ? SOL_LDS_STACK : SOL_NO_SPILL;
+  sol_search_context<true>(st, S);
   Counters cnt = {};
   const float inf = __builtin_huge_valf();
 
@@ -168,6 +171,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
   st.spill = (SOL_AS1 uint32_t*)spill + gtid;
   st.stride = P.total_threads;
   st.depth = SOL_LDS_STACK;
+  sol_search_context<false>(st, S);
   uint16_t* queue = lds_queue + wave_in_wg * SOL_POOL_MAX;
   const uint32_t NS = P.pool_slots;  // slots of this wave, a multiple of 64
   float4* const rec = pool + (size_t)wave * POOL_RECORDS * NS;
@@ -318,6 +322,7 @@ sol_debug_path_kernel(const DevScene S, const RenderParams P, uint32_t px, uint3
   st.spill = (SOL_AS1 uint32_t*)spill;
   st.stride = P.total_threads;
   st.depth = SOL_LDS_STACK;
+  sol_search_context<false>(st, S);
   Counters cnt = {};
   const float inf = __builtin_huge_valf();
   Path p = {};
@@ -349,10 +354,10 @@ hipError_t sol_launch_debug_path(const DevScene& S, const RenderParams& P, uint3
 }
 
 // ---- launch wrappers (called from sol_api.cpp) ----
-template <bool COUNT, bool MEDIUM>
+template <bool COUNT, bool MEDIUM, bool SPILL>
 static hipError_t launch_v1(const DevScene* dS, const RenderParams& P, float* acc, float* partial, uint32_t* work,
                             uint32_t* spill, DevCounters* cnt, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL((sol_render_kernel<COUNT, MEDIUM>), dim3(grid), dim3(SOL_WG), 0, stream, dS, P, acc, partial, work, spill, cnt);
+  hipLaunchKernelGGL((sol_render_kernel<COUNT, MEDIUM, SPILL>), dim3(grid), dim3(SOL_WG), 0, stream, dS, P, acc, partial, work, spill, cnt);
   return hipGetLastError();
 }
 template <bool COUNT, bool MEDIUM>
@@ -364,13 +369,15 @@ static hipError_t launch_v2(const DevScene& S, const RenderParams& P, float* acc
 }
 
 hipError_t sol_launch_render(int version, const DevScene& S, const DevScene* dS, const RenderParams& P, float* acc, float* partial, uint32_t* work,
-                             uint32_t* spill, void* pool, DevCounters* cnt, uint32_t grid, bool count, bool medium,
+                             uint32_t* spill, void* pool, DevCounters* cnt, uint32_t grid, bool count, bool medium, bool may_spill,
                              hipStream_t stream) {
   if (version == 1) {
-    if (count) return medium ? launch_v1<true, true>(dS, P, acc, partial, work, spill, cnt, grid, stream)
-                             : launch_v1<true, false>(dS, P, acc, partial, work, spill, cnt, grid, stream);
-    return medium ? launch_v1<false, true>(dS, P, acc, partial, work, spill, cnt, grid, stream)
-                  : launch_v1<false, false>(dS, P, acc, partial, work, spill, cnt, grid, stream);
+    if (count) return medium ? launch_v1<true, true, true>(dS, P, acc, partial, work, spill, cnt, grid, stream)
+                             : launch_v1<true, false, true>(dS, P, acc, partial, work, spill, cnt, grid, stream);
+    if (may_spill) return medium ? launch_v1<false, true, true>(dS, P, acc, partial, work, spill, cnt, grid, stream)
+                                 : launch_v1<false, false, true>(dS, P, acc, partial, work, spill, cnt, grid, stream);
+    return medium ? launch_v1<false, true, false>(dS, P, acc, partial, work, spill, cnt, grid, stream)
+                  : launch_v1<false, false, false>(dS, P, acc, partial, work, spill, cnt, grid, stream);
   }
   float4* pl = (float4*)pool;
   if (count) return medium ? launch_v2<true, true>(S, P, acc, partial, work, spill, pl, cnt, grid, stream)
@@ -386,9 +393,9 @@ static int blocks_per_cu(K kernel) {
   return n;
 }
 int sol_render_blocks_per_cu(int version, bool count, bool medium) {
-  if (version == 1) {
-    if (count) return medium ? blocks_per_cu(sol_render_kernel<true, true>) : blocks_per_cu(sol_render_kernel<true, false>);
-    return medium ? blocks_per_cu(sol_render_kernel<false, true>) : blocks_per_cu(sol_render_kernel<false, false>);
+  if (version == 1) {  // (the SPILL = false builds need no more registers or LDS than these)
+    if (count) return medium ? blocks_per_cu(sol_render_kernel<true, true, true>) : blocks_per_cu(sol_render_kernel<true, false, true>);
+    return medium ? blocks_per_cu(sol_render_kernel<false, true, true>) : blocks_per_cu(sol_render_kernel<false, false, true>);
   }
   if (count) return medium ? blocks_per_cu(sol_render_pool_kernel<true, true>) : blocks_per_cu(sol_render_pool_kernel<true, false>);
   return medium ? blocks_per_cu(sol_render_pool_kernel<false, true>) : blocks_per_cu(sol_render_pool_kernel<false, false>);

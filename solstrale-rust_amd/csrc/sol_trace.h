@@ -51,10 +51,28 @@ struct Stack {
   lds_u32* lds;              // base of this workgroup's [depth][SOL_WG] array, already offset by the lane
   SOL_AS1 uint32_t* spill;   // base of the global spill area, already offset by the global thread id
   uint32_t stride;           // total threads (spill stride between levels)
-  int depth;                 // entries per lane kept in LDS; deeper entries go to the spill area
+  int depth;                 // entries per lane kept in LDS; deeper entries go to the spill area. A kernel built for trees
+                             // that fit the LDS stack sets it to a huge constant: every spill branch folds away
+  // The three scene fields every step of a world search needs, copied out of the DevScene record once per kernel (sol_search_
+  // context): read through the record, the compiler re-loads them with s_load + s_waitcnt in front of EVERY node fetch (it has
+  // no scalar registers left to keep them), a scalar-cache round trip on the critical path of each visit.
+  const DWide* wides;
+  const DTri* tris;
+  uint32_t wide_emin;
 };
+// Fills the scene fields of a search context. PIN keeps the node fields in vector registers (3 VGPRs) by hiding where they came from.
+template <bool PIN>
+DEV void sol_search_context(Stack& st, const DevScene& S) {
+  unsigned long long w = (unsigned long long)S.wides, tr = (unsigned long long)S.tris;
+  uint32_t e = S.wide_emin;
+  if (PIN) asm volatile("" : "+v"(w), "+v"(e));  // (the triangle pointer too would cost the kernel its last registers: 3 spills)
+  st.wides = (const DWide*)w;
+  st.tris = (const DTri*)tr;
+  st.wide_emin = e;
+}
+#define SOL_NO_SPILL 0x3FFFFFFF  // Stack::depth of a kernel built for searches that fit the LDS stack (a compile-time constant there)
 DEV void stack_store(const Stack& s, int level, uint32_t v) {
-  if (level < s.depth) s.lds[level * SOL_WG] = v;
+  if (s.depth >= SOL_NO_SPILL || level < s.depth) s.lds[level * SOL_WG] = v;
   else s.spill[(size_t)(level - s.depth) * s.stride] = v;
 }
 DEV void stack_push(const Stack& s, int& sp, uint32_t v) {
@@ -64,7 +82,7 @@ DEV void stack_push(const Stack& s, int& sp, uint32_t v) {
 DEV uint32_t stack_pop(const Stack& s, int& sp) {
   sp--;
   uint32_t v;
-  if (sp < s.depth) v = s.lds[sp * SOL_WG];
+  if (s.depth >= SOL_NO_SPILL || sp < s.depth) v = s.lds[sp * SOL_WG];
   else v = s.spill[(size_t)(sp - s.depth) * s.stride];
   return v;
 }
@@ -223,11 +241,11 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
 // The slab tests of one fetched 7-wide node (h = origin + meta, qa / qb / qc = the six plane arrays) for the ray of search `t`:
 // the search's new node group and primitive group.
 template <bool COUNT>
-DEV void wide_node_test(const DevScene& S, Trav& t, uint32_t oct, float4 h, uint4 qa, uint4 qb, uint4 qc) {
+DEV void wide_node_test(uint32_t wide_emin, Trav& t, uint32_t oct, float4 h, uint4 qa, uint4 qb, uint4 qc) {
   const bool sx = (oct & 4u) != 0u, sy = (oct & 2u) != 0u, sz = (oct & 1u) != 0u;
   const uint32_t meta = __float_as_uint(h.w);
-  const float scx = __uint_as_float(((meta & 31u) + S.wide_emin) << 23), scy = __uint_as_float((((meta >> 5) & 31u) + S.wide_emin) << 23);
-  const float scz = __uint_as_float((((meta >> 10) & 31u) + S.wide_emin) << 23);
+  const float scx = __uint_as_float(((meta & 31u) + wide_emin) << 23), scy = __uint_as_float((((meta >> 5) & 31u) + wide_emin) << 23);
+  const float scz = __uint_as_float((((meta >> 10) & 31u) + wide_emin) << 23);
 #ifdef SOL_NO_TCULL
   const float cull_t = __builtin_huge_valf();
 #else
@@ -276,7 +294,7 @@ DEV void prim_test(const DevScene& S, Trav& t, const Stack& st, uint32_t kind, u
                    Counters& cnt) {
   const uint32_t ref = SOL_MAKE_REF(kind, idx);
   if (kind == SOL_REF_TRIANGLE) {
-    const float4* tp = reinterpret_cast<const float4*>(S.tris + idx);
+    const float4* tp = reinterpret_cast<const float4*>(st.tris + idx);
     const float4 p0 = ldg_f4(tp), p1 = ldg_f4(tp + 1), p2 = ldg_f4(tp + 2);
     DTri T;
     T.v0x = p0.x; T.v0y = p0.y; T.v0z = p0.z; T.e1x = p0.w; T.e1y = p1.x; T.e1z = p1.y; T.e2x = p1.z; T.e2y = p1.w; T.e2z = p2.x;
@@ -347,7 +365,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
         if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
       }
       t.g0 = 0u;  // (overwritten by the node test below)
-      addr = reinterpret_cast<const uint4*>(S.wides + idx);
+      addr = reinterpret_cast<const uint4*>(st.wides + idx);
       if (COUNT) cnt.node_visits++;
     } else if (act_prim) {
       const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
@@ -355,7 +373,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       const uint32_t lmask = (t.aux >> 5) & 0x7Fu, lkind = (t.aux >> 3) & 3u;
       pidx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(lmask & ((1u << slot) - 1u));
       pkind = lkind == SOL_LEAF_TRIANGLES ? SOL_REF_TRIANGLE : lkind == SOL_LEAF_SPHERES ? SOL_REF_SPHERE : lkind == SOL_LEAF_QUADS ? SOL_REF_QUAD : SOL_REF_NONE;
-      if (pkind == SOL_REF_TRIANGLE) addr = reinterpret_cast<const uint4*>(S.tris + pidx);
+      if (pkind == SOL_REF_TRIANGLE) addr = reinterpret_cast<const uint4*>(st.tris + pidx);
       else if (pkind == SOL_REF_SPHERE) addr = reinterpret_cast<const uint4*>(S.spheres + pidx);
     }
     if (addr != nullptr) {
@@ -364,7 +382,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       if (pkind != SOL_REF_SPHERE) r2 = ldg_u4(addr + 2);
       if (act_node) r3 = ldg_u4(addr + 3);
       if (act_node) {
-        wide_node_test<COUNT>(S, t, oct, make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w)), r1, r2, r3);
+        wide_node_test<COUNT>(st.wide_emin, t, oct, make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w)), r1, r2, r3);
       } else if (pkind == SOL_REF_TRIANGLE) {
         DTri T;
         T.v0x = __uint_as_float(r0.x); T.v0y = __uint_as_float(r0.y); T.v0z = __uint_as_float(r0.z); T.e1x = __uint_as_float(r0.w);
@@ -409,7 +427,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
         stack_push(st, t.sp, g1);
         if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
       }
-      const float4* wp = reinterpret_cast<const float4*>(S.wides + idx);
+      const float4* wp = reinterpret_cast<const float4*>(st.wides + idx);
       const float4 h = ldg_f4(wp);
       const uint4 qa = ldg_u4(wp + 1), qb = ldg_u4(wp + 2), qc = ldg_u4(wp + 3);
       if (COUNT) cnt.node_visits++;
@@ -436,7 +454,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
 #endif
       }
 #endif
-      wide_node_test<COUNT>(S, t, oct, h, qa, qb, qc);
+      wide_node_test<COUNT>(st.wide_emin, t, oct, h, qa, qb, qc);
     }
     // status for the callers' loops, and for the postponing rule below
     const bool has_prim = (t.pg >> 24) != 0u;

@@ -173,6 +173,7 @@ sol_wf_trace_kernel(const DevScene S, const RenderParams P, WfCounters* __restri
   Stack st;
   st.lds = (lds_u32*)lds_stack + tid;
   st.spill = (SOL_AS1 uint32_t*)spill + (blockIdx.x * SOL_WG + tid);
+  sol_search_context<false>(st, S);
   st.stride = P.total_threads;
   st.depth = SOL_LDS_STACK_TRACE;
   const size_t NS = P.pool_slots;
