@@ -67,7 +67,7 @@ int upload(const std::vector<T>& host, T** dev) {
 struct DevTree {
   DWide* wides = nullptr; uint32_t* leaf_refs = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
   DSphere* spheres = nullptr; DNode* nodes = nullptr; DMedium* mediums = nullptr; uint32_t* lights = nullptr;
-  uint32_t emin = 1, depth = 0, root = 0;
+  uint32_t emin = 1, depth = 0, root = 0, light0 = 0;
   std::vector<uint32_t> old_tri, old_sphere, old_quad;  // device index -> index in the caller's arrays
   void release() {
     void* p[] = {wides, leaf_refs, tris, tri_shade, quads, spheres, nodes, mediums, lights};
@@ -406,6 +406,10 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     o.kind = m.kind; o.albedo = m.albedo_tex; o.normal = m.normal_tex; o.m1 = m.m1; o.m2 = m.m2;
     o.param = (float)m.param;
     if (std::isnan(m.param)) o.flags |= DMAT_PARAM_NONE;
+    if (m.kind != SOL_MAT_BLEND && m.albedo_tex >= 0 && (uint32_t)m.albedo_tex < d->n_textures && texs[m.albedo_tex].kind == SOL_TEX_SOLID) {
+      o.flags |= DMAT_ALBEDO_SOLID;
+      o.ar = texs[m.albedo_tex].r; o.ag = texs[m.albedo_tex].g; o.ab = texs[m.albedo_tex].b;
+    }
     switch (m.kind) {
       case SOL_MAT_LAMBERTIAN: case SOL_MAT_METAL: case SOL_MAT_DIELECTRIC:
         if (!tex_ok(m.albedo_tex, false) || !tex_ok(m.normal_tex, true)) return fail(SOL_EINVAL, "material %u: bad texture id", i);
@@ -673,7 +677,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
       t.release();
       return e;
     }
-    t.emin = c.emin; t.depth = c.depth; t.root = L.remap(root_ref);
+    t.emin = c.emin; t.depth = c.depth; t.root = L.remap(root_ref); t.light0 = plights.empty() ? 0u : plights[0];
     t.old_tri = L.old_of_new[0]; t.old_sphere = L.old_of_new[1]; t.old_quad = L.old_of_new[2];
     return SOL_OK;
   };
@@ -683,7 +687,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     s->old_index[0] = std::move(t.old_tri); s->old_index[1] = std::move(t.old_sphere); s->old_index[2] = std::move(t.old_quad);
     DevScene& S = s->S;
     S.nodes = t.nodes; S.wides = t.wides; S.leaf_refs = t.leaf_refs; S.tris = t.tris; S.tri_shade = t.tri_shade; S.quads = t.quads; S.spheres = t.spheres;
-    S.mediums = t.mediums; S.lights = t.lights; S.wroot = 0; S.wide_emin = t.emin; S.root = t.root;
+    S.mediums = t.mediums; S.lights = t.lights; S.light0 = t.light0; S.wroot = 0; S.wide_emin = t.emin; S.root = t.root;
     s->tree_depth = t.depth;
     t = DevTree{};
   };
@@ -759,7 +763,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
       DevTree& back = cands[current].dev;
       back.nodes = s->nodes; back.wides = s->wides; back.leaf_refs = s->leaf_refs; back.tris = s->tris; back.tri_shade = s->tri_shade;
       back.quads = s->quads; back.spheres = s->spheres; back.mediums = s->mediums; back.lights = s->lights;
-      back.emin = S.wide_emin; back.depth = s->tree_depth; back.root = S.root;
+      back.emin = S.wide_emin; back.depth = s->tree_depth; back.root = S.root; back.light0 = S.light0;
       back.old_tri = std::move(s->old_index[0]); back.old_sphere = std::move(s->old_index[1]); back.old_quad = std::move(s->old_index[2]);
       adopt_tree(cands[k].dev);
       current = k;

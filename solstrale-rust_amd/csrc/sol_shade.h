@@ -33,6 +33,13 @@ DEV f3 tex_color(const DevScene& S, int id, float u, float v, Counters& cnt) {
   return mk3((float)ldg_u8(px) * s, (float)ldg_u8(px + 1) * s, (float)ldg_u8(px + 2) * s);
 }
 
+// The albedo colour of material record `m`: a solid colour sits in the record, an image goes through the texture record.
+template <bool COUNT>
+DEV f3 albedo_color(const DevScene& S, const DMat& m, float u, float v, Counters& cnt) {
+  if (m.flags & DMAT_ALBEDO_SOLID) return mk3(m.ar, m.ag, m.ab);
+  return tex_color<COUNT>(S, m.albedo, u, v, cnt);
+}
+
 // Geometry of the closest hit, recomputed from (ray, t, u, v) with the formulas of the primitives' `hit`.
 template <bool COUNT>
 DEV void build_surface(const DevScene& S, f3 o, f3 d, const Hit& h, const Rng& rng, uint32_t depth, Surface& sf) {
@@ -166,12 +173,13 @@ DEV f3 light_random_direction(const DevScene& S, uint32_t ref, f3 origin, Rng& r
 template <bool COUNT>
 DEV float container_pdf_value(const DevScene& S, f3 origin, f3 dir, Counters& cnt) {  // pdf.rs:89-96
   float sum = 0.0f;
+  if (S.n_lights == 1u) return light_pdf_value<COUNT>(S, S.light0, origin, dir, cnt) / 1.0f;  // (x / 1 == x: same value as the loop)
   for (uint32_t i = 0; i < S.n_lights; ++i) sum += light_pdf_value<COUNT>(S, ldg_u32(S.lights + i), origin, dir, cnt);
   return sum / (float)S.n_lights;
 }
 DEV f3 container_pdf_generate(const DevScene& S, f3 origin, Rng& rng) {  // pdf.rs:98-101
-  uint32_t i = rnd_index(rng, S.n_lights);
-  return light_random_direction(S, ldg_u32(S.lights + i), origin, rng);
+  uint32_t i = rnd_index(rng, S.n_lights);  // (the draw is consumed also when there is one light: same stream as the oracle)
+  return light_random_direction(S, S.n_lights == 1u ? S.light0 : ldg_u32(S.lights + i), origin, rng);
 }
 DEV f3 random_in_unit_sphere(Rng& rng) {  // vec3.rs:380-392 (bound never reached: (1-pi/6)^80)
   f3 p = mk3(0.f, 0.f, 0.f);
@@ -214,7 +222,7 @@ DEV void scatter(const DevScene& S, f3 ray_dir, const Surface& sf, Rng& rng, Sca
   sc.has_af = false; sc.af = 0.0f; sc.probability = 0.0f; sc.dir = mk3(0.f, 0.f, 0.f);
   if (m.kind == SOL_MAT_LAMBERTIAN) {
     sc.type = SCATTER_PDF;
-    sc.color = tex_color<COUNT>(S, m.albedo, sf.u, sf.v, cnt);
+    sc.color = albedo_color<COUNT>(S, m, sf.u, sf.v, cnt);
     Onb uvw = onb_new(sf.normal);  // CosinePdf::new (pdf.rs:58)
     f3 dir;
     if (rnd(rng) < 0.5f) dir = container_pdf_generate(S, sf.p, rng);  // mix_generate (pdf.rs:42-48)
@@ -229,7 +237,7 @@ DEV void scatter(const DevScene& S, f3 ray_dir, const Surface& sf, Rng& rng, Sca
   } else if (m.kind == SOL_MAT_METAL) {
     sc.type = SCATTER_BASIC;
     f3 reflected = reflect3(unit3(ray_dir), sf.normal);
-    sc.color = tex_color<COUNT>(S, m.albedo, sf.u, sf.v, cnt);
+    sc.color = albedo_color<COUNT>(S, m, sf.u, sf.v, cnt);
     sc.dir = reflected + random_in_unit_sphere(rng) * m.param;
   } else if (m.kind == SOL_MAT_DIELECTRIC) {
     sc.type = SCATTER_BASIC;
@@ -245,15 +253,15 @@ DEV void scatter(const DevScene& S, f3 ray_dir, const Surface& sf, Rng& rng, Sca
       refl = r0 + (1.0f - r0) * (x4 * x) > rnd(rng);
     }
     sc.dir = refl ? reflect3(ud, sf.normal) : refract3(ud, sf.normal, ratio);
-    sc.color = tex_color<COUNT>(S, m.albedo, sf.u, sf.v, cnt);
+    sc.color = albedo_color<COUNT>(S, m, sf.u, sf.v, cnt);
   } else if (m.kind == SOL_MAT_DIFFUSE_LIGHT) {
     sc.type = SCATTER_EMISSION;
-    sc.color = sf.front ? tex_color<COUNT>(S, m.albedo, sf.u, sf.v, cnt) : mk3(0.f, 0.f, 0.f);
+    sc.color = sf.front ? albedo_color<COUNT>(S, m, sf.u, sf.v, cnt) : mk3(0.f, 0.f, 0.f);
     sc.has_af = !(m.flags & DMAT_PARAM_NONE);
     sc.af = m.param;
   } else {  // SOL_MAT_ISOTROPIC
     sc.type = SCATTER_PDF;
-    sc.color = tex_color<COUNT>(S, m.albedo, sf.u, sf.v, cnt);
+    sc.color = albedo_color<COUNT>(S, m, sf.u, sf.v, cnt);
     f3 dir;
     if (rnd(rng) < 0.5f) dir = container_pdf_generate(S, sf.p, rng);
     else dir = unit3(random_in_unit_sphere(rng));  // SpherePdf::generate (pdf.rs:121-124)

@@ -127,17 +127,22 @@ struct __attribute__((aligned(16))) DMedium {
 };
 static_assert(sizeof(DMedium) == 48, "DMedium");
 
-// 32-byte material record (src/material/mod.rs:134-150)
+// 48-byte material record (src/material/mod.rs:134-150). A SolidColor albedo texture (texture.rs:101) is copied into the record:
+// shading a hit is a chain of dependent fetches (shading record -> material -> texture -> texel -> light), and for a solid
+// colour the texture record is one link less.
 struct __attribute__((aligned(16))) DMat {
   int32_t kind, albedo, normal, m1;
   int32_t m2;
   float param;
-  uint32_t flags;  // bit0: param is None (DiffuseLight.attenuation_factor); bit1: some texture below is an image
-  uint32_t pad;
+  uint32_t flags;  // bit0: param is None (DiffuseLight.attenuation_factor); bit1: some texture below is an image; bit2: the albedo
+  uint32_t pad;    //       texture is a solid colour, held in ar / ag / ab
+  float ar, ag, ab;
+  uint32_t pad2;
 };
-static_assert(sizeof(DMat) == 32, "DMat");
+static_assert(sizeof(DMat) == 48, "DMat");
 #define DMAT_PARAM_NONE 1u
 #define DMAT_NEEDS_UV 2u
+#define DMAT_ALBEDO_SOLID 4u
 
 // 32-byte texture record (src/material/texture.rs:101,128-133)
 struct __attribute__((aligned(16))) DTex {
@@ -167,6 +172,7 @@ struct DevScene {
   const uint8_t* texels;
   const uint32_t* lights;
   uint32_t n_lights;
+  uint32_t light0;      // the light's reference when there is exactly one (saves the dependent fetch of lights[0] per bounce)
   uint32_t root;                                          // device reference of the world
   float rxmin, rxmax, rymin, rymax, rzmin, rzmax;         // world root box (Bvh::hit's own b_box test)
   uint32_t width, height, shader, max_depth;

@@ -44,7 +44,7 @@ def test_struct_layouts_match_the_c_side():
 def test_device_record_sizes():
     from solstrale_amd import record_sizes
     # node = the 7-wide quantised node the world is searched through (64 B: half a cache line, implicit child addresses)
-    assert record_sizes() == {"node": 64, "sphere": 32, "quad": 80, "triangle": 48, "triangle_shade": 64, "material": 32}
+    assert record_sizes() == {"node": 64, "sphere": 32, "quad": 80, "triangle": 48, "triangle_shade": 64, "material": 48}
 
 
 def test_hip_library_is_a_gfx950_code_object():
