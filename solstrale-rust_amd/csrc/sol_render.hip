@@ -109,9 +109,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         if (COUNT) item_rays0 = cnt.rays;
       }
       if (!alive) {
-#ifndef SOL_PHASE_EXP
         phase_tick<COUNT>(cnt, 2);
-#endif
         generate_path<COUNT>(S, P.seed_lo, P.seed_hi, it.px, it.py, s, p, cnt);
         alive = true;
       }
