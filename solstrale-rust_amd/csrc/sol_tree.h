@@ -530,12 +530,84 @@ struct WideLayout {
     return true;
   }
   // the device build (sol_build.hip) delivers nodes, leaf_refs and new_of_old: derive the inverse maps and check them
+  // Re-lays a device-built tree out in depth-first order (as run() does for the host-built ones): the GPU emission reserves
+  // indices with atomics, so the ORDER of nodes and primitives in memory differs from run to run while the tree does not;
+  // after this pass the layout is a function of the tree alone (reproducible timings), and sub-trees are contiguous.
+  bool canonicalize() {
+    const uint32_t counts[3] = {(uint32_t)new_of_old[0].size(), (uint32_t)new_of_old[1].size(), (uint32_t)new_of_old[2].size()};
+    std::vector<uint32_t> cur2new[3];
+    for (int a = 0; a < 3; ++a) cur2new[a].assign(counts[a], 0xFFFFFFFFu);
+    uint32_t next_prim[3] = {0, 0, 0};
+    std::vector<DWide> out(1);
+    out.reserve(nodes.size());
+    std::vector<uint32_t> refs_out;
+    refs_out.reserve(leaf_refs.size());
+    const uint32_t ref_kind_of[4] = {SOL_REF_NONE, SOL_REF_TRIANGLE, SOL_REF_SPHERE, SOL_REF_QUAD};
+    struct Item { uint32_t from, to; };
+    std::vector<Item> stk{{0u, 0u}};
+    auto place = [&](int a, uint32_t cur) -> uint32_t {
+      if (a < 0 || cur >= counts[a] || cur2new[a][cur] != 0xFFFFFFFFu) { error = "device tree: a primitive is referenced twice or out of range"; return 0xFFFFFFFFu; }
+      return cur2new[a][cur] = next_prim[a]++;
+    };
+    while (!stk.empty()) {
+      const Item it = stk.back();
+      stk.pop_back();
+      if (it.from >= nodes.size()) { error = "device tree: node index out of range"; return false; }
+      DWide w = nodes[it.from];
+      const uint32_t imask = (w.meta >> 15) & 0x7Fu, lmask = (w.meta >> 22) & 0x7Fu, kind = (w.meta >> 29) & 3u;
+      const uint32_t n_inner = (uint32_t)__builtin_popcount(imask), n_leaf = (uint32_t)__builtin_popcount(lmask);
+      const uint32_t bi_from = base_inner(w), bp_from = base_prim(w);
+      const uint32_t bi_to = n_inner ? (uint32_t)out.size() : 0u;
+      out.resize(out.size() + n_inner);
+      uint32_t bp_to = 0;
+      if (n_leaf) {
+        if (kind == SOL_LEAF_REFS) {
+          bp_to = (uint32_t)refs_out.size();
+          for (uint32_t r = 0; r < n_leaf; ++r) {
+            if (bp_from + r >= leaf_refs.size()) { error = "device tree: listed reference out of range"; return false; }
+            uint32_t ref = leaf_refs[bp_from + r];
+            const int a = arr(SOL_REF_KIND(ref));
+            if (a >= 0) {
+              const uint32_t n = place(a, SOL_REF_INDEX(ref));
+              if (n == 0xFFFFFFFFu) return false;
+              ref = SOL_MAKE_REF(SOL_REF_KIND(ref), n);
+            }
+            refs_out.push_back(ref);
+          }
+        } else {
+          const int a = arr(ref_kind_of[kind]);
+          bp_to = next_prim[a];
+          for (uint32_t r = 0; r < n_leaf; ++r)
+            if (place(a, bp_from + r) == 0xFFFFFFFFu) return false;
+        }
+      }
+      for (int k = 0; k < 3; ++k) {
+        w.q[2 * k + 1] = (w.q[2 * k + 1] & 0x00FFFFFFu) | (((bi_to >> (8 * k)) & 0xFFu) << 24);
+        w.q[6 + 2 * k + 1] = (w.q[6 + 2 * k + 1] & 0x00FFFFFFu) | (((bp_to >> (8 * k)) & 0xFFu) << 24);
+      }
+      out[it.to] = w;
+      for (uint32_t r = n_inner; r-- > 0;) stk.push_back(Item{bi_from + r, bi_to + r});  // first child's sub-tree right behind the siblings
+    }
+    if (out.size() != nodes.size()) { error = "device tree: unreachable nodes"; return false; }
+    for (int a = 0; a < 3; ++a)  // primitives outside the world tree: behind the others, in the caller's order
+      for (uint32_t old = 0; old < counts[a]; ++old) {
+        const uint32_t cur = new_of_old[a][old];
+        if (cur >= counts[a]) { error = "device tree: the primitive map is not a permutation"; return false; }
+        if (cur2new[a][cur] == 0xFFFFFFFFu) cur2new[a][cur] = next_prim[a]++;
+      }
+    for (int a = 0; a < 3; ++a)
+      for (uint32_t old = 0; old < counts[a]; ++old) new_of_old[a][old] = cur2new[a][new_of_old[a][old]];
+    nodes.swap(out);
+    leaf_refs.swap(refs_out);
+    return true;
+  }
   bool adopt_device(std::vector<DWide>&& n, std::vector<uint32_t>&& refs, std::vector<uint32_t> (&no)[3], uint32_t levels) {
     nodes = std::move(n);
     leaf_refs = std::move(refs);
     depth = levels;
+    for (int a = 0; a < 3; ++a) new_of_old[a] = std::move(no[a]);
+    if (nodes.empty() || !canonicalize()) return false;
     for (int a = 0; a < 3; ++a) {
-      new_of_old[a] = std::move(no[a]);
       old_of_new[a].assign(new_of_old[a].size(), 0xFFFFFFFFu);
       for (uint32_t i = 0; i < new_of_old[a].size(); ++i) {
         const uint32_t k = new_of_old[a][i];
