@@ -96,6 +96,37 @@ def test_device_built_tree_renders_the_same_frames():
         assert bt["device_tree"] > 0 and bt["probes"] < bt["device_tree"] + 1.0
 
 
+def test_ties_keep_hit_and_material_together():
+    """Hits at EXACTLY equal t: the reference keeps the later primitive in depth-first leaf order (bvh.rs:172-178 with the
+    inclusive Interval::contains). Coincident primitives of different colours make every hit a tie: geometry AND material must
+    come from the later one, for quads, triangles and spheres, whichever is tested first (both orders are built). (An experiment
+    that carried the material index in the hit record lost it exactly here - DESIGN.md 9 - and only a 2-pixel CRC difference
+    of a full frame showed it: hence this test.)"""
+    for order in (0, 1):
+        b = SceneBuilder()
+        red, white = b.Lambertian(b.SolidColor(1., 0., 0.)), b.Lambertian(b.SolidColor(.9, .9, .9))
+        m = (red, white) if order == 0 else (white, red)
+        world = []
+        for k in range(2):  # the same quad, triangle and sphere twice: the second (later leaf) must win everywhere
+            world.append(b.Quad((-3., 0., -3.), (2., 0., 0.), (0., 2., 0.), m[k]))
+            world.append(b.Triangle((0., 0., -3.), (2., 0., -3.), (1., 2., -3.), m[k]))
+            world.append(b.Sphere((3.5, 1., -3.), 1., m[k]))
+        world.append(b.Sphere((0., 50., 20.), 10., b.DiffuseLight(5, 5, 5)))
+        cam = CameraConfig(50., 0., (0.5, 1., 4.), (0.5, 1., -3.), (0, 1, 0))
+        sc = b.finish(b.Bvh(world), cam, (.1, .1, .1), RenderConfig(160, 80, 4, AlbedoShader()))
+        img = gpu_render(sc, 4)
+        ref, _ = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F32)
+        assert pu.compare(img, ref, 4)["bad_pixels"] == 0
+        want = np.array([1., 0., 0.] if order == 1 else [.9, .9, .9], dtype=np.float32) * 4
+        inside = np.abs(ref - want.astype(np.float64)).max(axis=-1) < 1e-5  # pixels whose four samples all hit a primitive
+        assert inside.sum() > 1000 and np.allclose(img[inside], want, atol=1e-5), order
+        loser = np.array([.9, .9, .9] if order == 1 else [1., 0., 0.]) * 4
+        assert not (np.abs(img - loser).max(axis=-1) < 1e-5).any()  # the earlier primitive's colour shows nowhere
+        # and through the path-tracing shader (materials feed the throughput)
+        sc2 = b.finish(b.Bvh(world), cam, (.1, .1, .1), RenderConfig(160, 80, 8))
+        assert_parity(sc2, 8)
+
+
 def test_heavy_first_work_order_changes_nothing(monkeypatch):
     """Scenes with long paths (glass) get their costly pixel blocks scheduled first (cost probe at scene creation,
     sol_path.h decode_item_ordered); the frame must be the one of the plain order, for one rank and for a partition."""
