@@ -1,0 +1,80 @@
+"""Creation and scheduling options through the C ABI (sol_scene_create_ex, sol_scene_set_option; no reference analogue: the
+reference has one BVH builder and no scheduler to tune). None of them may change a frame."""
+import numpy as np
+import pytest
+
+import parity_util as pu
+from solstrale_amd import DeviceError, DeviceScene, RenderConfig, _abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(ds, spp=16):
+    ds.clear()
+    ds.render(0, spp, pu.SEED)
+    return ds.read()
+
+
+@pytest.mark.parametrize("make", [scenes.cornell_spheres, scenes.sponza_like, scenes.create_test_scene], ids=["c2", "c3", "test"])
+def test_every_world_tree_choice_renders_the_same_frame(make):
+    sc = make(RenderConfig(240, 136, 16))
+    frames = {}
+    for tree in (_abi.TREE_AUTO, _abi.TREE_REF, _abi.TREE_SAH8, _abi.TREE_SAH16, _abi.TREE_SAH64, _abi.TREE_DEVICE, _abi.TREE_HOST_PROBE):
+        with DeviceScene(sc, world_tree=tree) as ds:
+            frames[tree] = _frame(ds)
+            bt = ds.build_times()
+            assert (bt["device_tree"] > 0) == (tree in (_abi.TREE_AUTO, _abi.TREE_DEVICE)), (tree, bt)
+    for tree, img in frames.items():
+        assert (img == frames[_abi.TREE_AUTO]).all(), tree
+
+
+def test_scheduler_options_do_not_change_the_frame():
+    sc = scenes.sponza_like(RenderConfig(240, 136, 16))
+    with DeviceScene(sc) as ds:
+        want = _frame(ds)
+        for opt, values in ((_abi.OPT_SWITCH_BELOW, (0, 8, 40, 64)), (_abi.OPT_MAX_BLOCKS_PER_CU, (1, 2, 0)), (_abi.OPT_WORK_ORDER, (0, 1)),
+                            (_abi.OPT_KERNEL, (2, 3, 1, 0))):
+            for v in values:
+                ds.set_option(opt, v)
+                assert (_frame(ds) == want).all(), (opt, v)
+        for opt, v in ((_abi.OPT_SWITCH_BELOW, 65), (_abi.OPT_SWITCH_BELOW, -1), (_abi.OPT_KERNEL, 4), (99, 0)):
+            with pytest.raises(DeviceError) as e:
+                ds.set_option(opt, v)
+            assert e.value.code == _abi.SOL_EINVAL
+        assert (_frame(ds) == want).all()
+
+
+def test_creation_without_the_work_order_probe():
+    """`no_work_order_probe` (an EverySample preview that must start at once): no counted 4-spp probe of the frame at creation."""
+    sc = scenes.statue_like(RenderConfig(480, 270, 16), n_triangles=60000)
+    with DeviceScene(sc) as ds:
+        want, with_probe = _frame(ds), ds.build_times()["probes"]
+    with DeviceScene(sc, no_work_order_probe=True) as ds:
+        assert (_frame(ds) == want).all()
+        assert ds.build_times()["probes"] < with_probe
+
+
+def test_bad_creation_options_are_rejected():
+    sc = scenes.cornell_box(RenderConfig(32, 32, 1))
+    with pytest.raises(DeviceError) as e:
+        DeviceScene(sc, world_tree=17)
+    assert e.value.code == _abi.SOL_EINVAL
+
+
+def test_rebinding_rules_of_a_caller_bound_accumulator():
+    """sol_scene_set_partition refuses to drop a caller-bound accumulator silently (it would keep gathering from a buffer that
+    is no longer written)."""
+    import torch
+    sc = scenes.cornell_box(RenderConfig(64, 64, 4))
+    with DeviceScene(sc) as ds:
+        n = ds.accum_floats()
+        buf = torch.zeros(n, dtype=torch.float32, device="cuda")
+        ds.bind_accum(buf.data_ptr(), n)
+        ds.set_partition(0, 1)  # same size: allowed, the binding stays
+        with pytest.raises(DeviceError) as e:
+            ds.set_partition(1, 2)
+        assert e.value.code == _abi.SOL_EINVAL and "unbind" in e.value.msg
+        ds.bind_accum(0, 0)
+        ds.set_partition(1, 2)
+        ds.render(0, 4, pu.SEED)
+        assert np.isfinite(ds.read()).all()
