@@ -44,6 +44,13 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
   st.stride = P.total_threads;
   st.depth = SPILL ? SOL_LDS_STACK : SOL_NO_SPILL;
   sol_search_context<true>(st, S);
+#ifndef SOL_NO_OCT_TABLE
+  __shared__ uint8_t oct_table[SOL_OCT_TABLE_BYTES];
+  sol_fill_oct_table((lds_u8*)oct_table, tid, SOL_WG);
+  st.oct_table = (const lds_u8*)oct_table;
+  st.oct_table_on = true;
+  __syncthreads();
+#endif
   Counters cnt = {};
   const float inf = __builtin_huge_valf();
 

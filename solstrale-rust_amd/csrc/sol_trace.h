@@ -47,6 +47,8 @@ DEV void phase_tick(Counters& cnt, int ph) {
 // The two halves of the stack live in different address spaces and are typed so: a pointer chosen between them at run time
 // would be generic, and the pop of EVERY step a flat_load (vmcnt + lgkmcnt, aperture check) instead of a ds_read.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+#define SOL_OCT_TABLE_BYTES 1024  // [octant][7-bit slot mask] -> the mask in visit order (sol_fill_oct_table)
 struct Stack {
   lds_u32* lds;              // base of this workgroup's [depth][SOL_WG] array, already offset by the lane
   SOL_AS1 uint32_t* spill;   // base of the global spill area, already offset by the global thread id
@@ -59,7 +61,21 @@ struct Stack {
   const DWide* wides;
   const DTri* tris;
   uint32_t wide_emin;
+  // Slot mask -> visit-order mask of a 7-wide node (bit p <- bit p ^ octant) as a 1 KiB table in LDS, or nullptr-equivalent
+  // (oct_table_on = false): three conditional butterfly stages, 14 four-cycle vector instructions per node visit. The kernel is
+  // bound by vector-instruction issue and its LDS pipe idles, so the render kernel trades them for one ds_read_u8.
+  const lds_u8* oct_table;
+  bool oct_table_on;
 };
+// Fills a workgroup's octant table (all threads call it; the caller synchronises the workgroup before the first search).
+DEV void sol_fill_oct_table(lds_u8* tbl, uint32_t tid, uint32_t n_threads) {
+  for (uint32_t i = tid; i < SOL_OCT_TABLE_BYTES; i += n_threads) {
+    const uint32_t oct = i >> 7, m = i & 127u;
+    uint32_t r = 0u;
+    for (uint32_t p = 0; p < 8u; ++p) r |= ((m >> (p ^ oct)) & 1u) << p;
+    tbl[i] = (uint8_t)r;
+  }
+}
 // Fills the scene fields of a search context. PIN keeps the node fields in vector registers (3 VGPRs) by hiding where they came from.
 template <bool PIN>
 DEV void sol_search_context(Stack& st, const DevScene& S) {
@@ -69,6 +85,8 @@ DEV void sol_search_context(Stack& st, const DevScene& S) {
   st.wides = (const DWide*)w;
   st.tris = (const DTri*)tr;
   st.wide_emin = e;
+  st.oct_table = nullptr;
+  st.oct_table_on = false;
 }
 #define SOL_NO_SPILL 0x3FFFFFFF  // Stack::depth of a kernel built for searches that fit the LDS stack (a compile-time constant there)
 DEV void stack_store(const Stack& s, int level, uint32_t v) {
@@ -241,7 +259,8 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
 // The slab tests of one fetched 7-wide node (h = origin + meta, qa / qb / qc = the six plane arrays) for the ray of search `t`:
 // the search's new node group and primitive group.
 template <bool COUNT>
-DEV void wide_node_test(uint32_t wide_emin, Trav& t, uint32_t oct, float4 h, uint4 qa, uint4 qb, uint4 qc) {
+DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 qa, uint4 qb, uint4 qc) {
+  const uint32_t wide_emin = st.wide_emin;
   const bool sx = (oct & 4u) != 0u, sy = (oct & 2u) != 0u, sz = (oct & 1u) != 0u;
   const uint32_t meta = __float_as_uint(h.w);
   const float scx = __uint_as_float(((meta & 31u) + wide_emin) << 23), scy = __uint_as_float((((meta >> 5) & 31u) + wide_emin) << 23);
@@ -275,9 +294,12 @@ DEV void wide_node_test(uint32_t wide_emin, Trav& t, uint32_t oct, float4 h, uin
   const uint32_t imask = (meta >> 15) & 0x7Fu, lmask = (meta >> 22) & 0x7Fu;
   // inner hits into visit order: bit p <- bit p ^ octant (three conditional butterfly stages)
   uint32_t ih = hits & imask;
+  if (st.oct_table_on) ih = st.oct_table[(oct << 7) | ih];
+  else {
   ih = (oct & 1u) ? (((ih & 0x55u) << 1) | ((ih >> 1) & 0x55u)) : ih;
   ih = (oct & 2u) ? (((ih & 0x33u) << 2) | ((ih >> 2) & 0x33u)) : ih;
   ih = (oct & 4u) ? (((ih & 0x0Fu) << 4) | (ih >> 4)) : ih;
+  }
   // base indices ride in the slot-7 bytes of the six plane arrays (lo x, y, z: inner; hi x, y, z: primitives)
   const uint32_t base_inner = (qa.y >> 24) | ((qa.w >> 24) << 8) | ((qb.y >> 24) << 16);
   const uint32_t base_prim = (qb.w >> 24) | ((qc.y >> 24) << 8) | ((qc.w >> 24) << 16);
@@ -382,7 +404,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       if (pkind != SOL_REF_SPHERE) r2 = ldg_u4(addr + 2);
       if (act_node) r3 = ldg_u4(addr + 3);
       if (act_node) {
-        wide_node_test<COUNT>(st.wide_emin, t, oct, make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w)), r1, r2, r3);
+        wide_node_test<COUNT>(st, t, oct, make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w)), r1, r2, r3);
       } else if (pkind == SOL_REF_TRIANGLE) {
         DTri T;
         T.v0x = __uint_as_float(r0.x); T.v0y = __uint_as_float(r0.y); T.v0z = __uint_as_float(r0.z); T.e1x = __uint_as_float(r0.w);
@@ -454,7 +476,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
 #endif
       }
 #endif
-      wide_node_test<COUNT>(st.wide_emin, t, oct, h, qa, qb, qc);
+      wide_node_test<COUNT>(st, t, oct, h, qa, qb, qc);
     }
     // status for the callers' loops, and for the postponing rule below
     const bool has_prim = (t.pg >> 24) != 0u;
