@@ -190,12 +190,12 @@ DEV bool better(float t, uint32_t dfs, const Hit& h) {
 //
 // Searches of the 2-wide tree (constant-medium boundaries; BINARY) keep one reference per stack entry and `cur` = the
 // reference being visited. Searches of the 7-wide tree (the world) keep GROUPS, after Ylitie, Karras & Laine (2017, sec. 5):
-//   node group  g0 = base_inner | ordered hits << 24,  g1 = imask  - the inner children of one node that the ray's slab test
+//   node group  g0 = base_inner | ordered hits << 24,  g1 = the node's meta word (imask)  - the inner children of one node that the ray's slab test
 //               hit and that have not been visited yet. "Ordered": bit p stands for slot p ^ octant, so the lowest set bit is
 //               the nearest child. Visiting a child pushes what is left of its parent's group: ONE two-dword stack entry per
 //               level instead of one entry per child (the first layout: eight ds_write_b32 and ~70 placement instructions per
 //               visit).
-//   prim group  pg = base_prim | hit leaf slots << 24,  aux = octant | leaf kind << 3 | lmask << 5 - the hit primitives of
+//   prim group  pg = base_prim | hit leaf slots << 24  (leaf kind and lmask: g1, the same node's meta word) - the hit primitives of
 //               the node visited last; they are tested before the search descends further.
 // `cur` is only the status of such a search: REF_DONE when it is over, 0 while it runs.
 struct Trav {
@@ -203,7 +203,7 @@ struct Trav {
   float tmin;
   uint32_t cur;
   int sp, sp_base;
-  uint32_t g0, g1, pg, aux;  // (7-wide searches only)
+  uint32_t g0, g1, pg, oct;  // (7-wide searches only; oct = the ray's octant, sign bits of the direction as x<<2 | y<<1 | z)
   Hit h;
 };
 
@@ -224,7 +224,7 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
   t.g0 = root | (1u << 24);
   t.g1 = 0u;
   t.pg = 0u;
-  t.aux = (__builtin_signbitf(t.inv.x) ? 4u : 0u) | (__builtin_signbitf(t.inv.y) ? 2u : 0u) | (__builtin_signbitf(t.inv.z) ? 1u : 0u);
+  t.oct = (__builtin_signbitf(t.inv.x) ? 4u : 0u) | (__builtin_signbitf(t.inv.y) ? 2u : 0u) | (__builtin_signbitf(t.inv.z) ? 1u : 0u);
   // A ray with a NaN in its origin or direction cannot hit anything: every primitive test ends in a comparison with NaN,
   // which is false (the reference returns None the same way, after visiting every box - Aabb::hit ignores NaN). Such rays
   // occur a few times per 10^8 samples; without this exit one lane walks the whole tree and tests every primitive.
@@ -301,12 +301,12 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   ih = (oct & 4u) ? (((ih & 0x0Fu) << 4) | (ih >> 4)) : ih;
   }
   // base indices ride in the slot-7 bytes of the six plane arrays (lo x, y, z: inner; hi x, y, z: primitives)
-  const uint32_t base_inner = (qa.y >> 24) | ((qa.w >> 24) << 8) | ((qb.y >> 24) << 16);
-  const uint32_t base_prim = (qb.w >> 24) | ((qc.y >> 24) << 8) | ((qc.w >> 24) << 16);
+  // (two byte permutes each: {top of a, top of b, 0, 0}, then {.., .., top of c, 0})
+  const uint32_t base_inner = __builtin_amdgcn_perm(qb.y, __builtin_amdgcn_perm(qa.w, qa.y, 0x0C0C0703u), 0x0C070100u);
+  const uint32_t base_prim = __builtin_amdgcn_perm(qc.w, __builtin_amdgcn_perm(qc.y, qb.w, 0x0C0C0703u), 0x0C070100u);
   t.g0 = base_inner | (ih << 24);
-  t.g1 = imask;
+  t.g1 = meta;  // (imask, lmask and leaf kind are read from it where they are needed)
   t.pg = base_prim | ((hits & lmask) << 24);
-  t.aux = oct | ((meta >> 29) << 3) | (lmask << 5);
 }
 
 // Tests primitive `idx` of kind `kind` against the search's interval [tmin, best t] and keeps it when it is the better hit
@@ -354,86 +354,7 @@ template <bool COUNT, bool MEDIUM, bool BINARY>
 DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
   phase_tick<COUNT>(cnt, 0);
   if (!BINARY) {
-    const uint32_t oct = t.aux & 7u;
-#if SOL_UNIFIED_STEP
-    // One fetch per step: a lane either visits a node (no pending primitives) or tests one pending triangle / sphere; both
-    // fetch up to 64 bytes into the same registers, so the wave waits for memory ONCE per step, not once for its node lanes and
-    // once more for its primitive lanes. Primitives found by this step's node tests wait for the next step (where they add to
-    // the lanes that make a primitive round worth its instructions); quads and listed references take the general path.
-    const bool prim0 = (t.pg >> 24) != 0u;
-    bool do_prims = true;
-#if SOL_PRIM_MIN > 1
-    {
-      const unsigned long long pm = __ballot(prim0), im = __ballot(!prim0);
-      do_prims = im == 0ull || (int)__popcll(pm) >= SOL_PRIM_MIN;  // (wave-uniform) postponed primitive tests, as below
-    }
-#endif
-    const bool act_node = !prim0, act_prim = prim0 && do_prims;
-    const uint4* addr = nullptr;
-    uint32_t pkind = SOL_REF_NONE, pidx = 0u;
-    if (act_node) {
-      uint32_t g0 = t.g0, g1 = t.g1;
-      if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
-        g1 = stack_pop(st, t.sp);
-        g0 = stack_pop(st, t.sp);
-      }
-      const uint32_t p = (uint32_t)__builtin_ctz(g0 >> 24);  // nearest: lowest bit in visit order
-      const uint32_t slot = p ^ oct;
-      g0 &= ~(1u << (24u + p));
-      const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc(g1 & ((1u << slot) - 1u));
-      if ((g0 >> 24) != 0u) {  // siblings left: one stack entry for all of them
-        stack_push(st, t.sp, g0);
-        stack_push(st, t.sp, g1);
-        if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
-      }
-      t.g0 = 0u;  // (overwritten by the node test below)
-      addr = reinterpret_cast<const uint4*>(st.wides + idx);
-      if (COUNT) cnt.node_visits++;
-    } else if (act_prim) {
-      const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
-      t.pg &= ~(1u << (24u + slot));
-      const uint32_t lmask = (t.aux >> 5) & 0x7Fu, lkind = (t.aux >> 3) & 3u;
-      pidx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(lmask & ((1u << slot) - 1u));
-      pkind = lkind == SOL_LEAF_TRIANGLES ? SOL_REF_TRIANGLE : lkind == SOL_LEAF_SPHERES ? SOL_REF_SPHERE : lkind == SOL_LEAF_QUADS ? SOL_REF_QUAD : SOL_REF_NONE;
-      if (pkind == SOL_REF_TRIANGLE) addr = reinterpret_cast<const uint4*>(st.tris + pidx);
-      else if (pkind == SOL_REF_SPHERE) addr = reinterpret_cast<const uint4*>(S.spheres + pidx);
-    }
-    if (addr != nullptr) {
-      const uint4 r0 = ldg_u4(addr), r1 = ldg_u4(addr + 1);
-      uint4 r2 = make_uint4(0u, 0u, 0u, 0u), r3 = make_uint4(0u, 0u, 0u, 0u);
-      if (pkind != SOL_REF_SPHERE) r2 = ldg_u4(addr + 2);
-      if (act_node) r3 = ldg_u4(addr + 3);
-      if (act_node) {
-        wide_node_test<COUNT>(st, t, oct, make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w)), r1, r2, r3);
-      } else if (pkind == SOL_REF_TRIANGLE) {
-        DTri T;
-        T.v0x = __uint_as_float(r0.x); T.v0y = __uint_as_float(r0.y); T.v0z = __uint_as_float(r0.z); T.e1x = __uint_as_float(r0.w);
-        T.e1y = __uint_as_float(r1.x); T.e1z = __uint_as_float(r1.y); T.e2x = __uint_as_float(r1.z); T.e2y = __uint_as_float(r1.w);
-        T.e2z = __uint_as_float(r2.x);
-        const uint32_t dfs = r2.y;
-        if (COUNT) cnt.triangle_tests++;
-        float tt, u, v;
-        if (tri_test(T, t.o, t.d, t.tmin, t.h.t, tt, u, v) && better(tt, dfs, t.h)) { t.h.t = tt; t.h.ref = SOL_MAKE_REF(SOL_REF_TRIANGLE, pidx); t.h.dfs = dfs; t.h.u = u; t.h.v = v; }
-      } else {
-        DSphere Sp;
-        Sp.cx = __uint_as_float(r0.x); Sp.cy = __uint_as_float(r0.y); Sp.cz = __uint_as_float(r0.z); Sp.radius = __uint_as_float(r0.w);
-        Sp.dfs = r1.x; Sp.mat = (int32_t)r1.y;
-        if (COUNT) cnt.sphere_tests++;
-        float tt;
-        if (sphere_test(Sp, t.o, t.d, t.tmin, t.h.t, S.sphere_slack, tt) && better(tt, Sp.dfs, t.h)) { t.h.t = tt; t.h.ref = SOL_MAKE_REF(SOL_REF_SPHERE, pidx); t.h.dfs = Sp.dfs; }
-      }
-    } else if (act_prim) {  // quads (80-byte records), listed references (a second, dependent fetch), mediums
-      uint32_t kind = pkind, idx = pidx;
-      if (pkind == SOL_REF_NONE) {
-        const uint32_t r = ldg_u32(S.leaf_refs + pidx);
-        kind = SOL_REF_KIND(r);
-        idx = SOL_REF_INDEX(r);
-      }
-      prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
-    }
-    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
-    return;
-#else
+    const uint32_t oct = t.oct;
     if ((t.pg >> 24) == 0u) {
       uint32_t g0 = t.g0, g1 = t.g1;
       if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
@@ -443,7 +364,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       const uint32_t p = (uint32_t)__builtin_ctz(g0 >> 24);  // nearest: lowest bit in visit order
       const uint32_t slot = p ^ oct;
       g0 &= ~(1u << (24u + p));
-      const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc(g1 & ((1u << slot) - 1u));
+      const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc((g1 >> 15) & ((1u << slot) - 1u));  // rank among the node's inner children (imask)
       if ((g0 >> 24) != 0u) {  // siblings left: one stack entry for all of them
         stack_push(st, t.sp, g0);
         stack_push(st, t.sp, g1);
@@ -494,8 +415,8 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
 #endif
     const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
     t.pg &= ~(1u << (24u + slot));
-    const uint32_t lmask = (t.aux >> 5) & 0x7Fu, lkind = (t.aux >> 3) & 3u;
-    uint32_t idx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(lmask & ((1u << slot) - 1u));
+    const uint32_t lkind = t.g1 >> 29;  // (no group was popped since this node's test: a lane with pending primitives skips part 1)
+    uint32_t idx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc((t.g1 >> 22) & ((1u << slot) - 1u));
     uint32_t kind = lkind == SOL_LEAF_TRIANGLES ? SOL_REF_TRIANGLE : lkind == SOL_LEAF_SPHERES ? SOL_REF_SPHERE : SOL_REF_QUAD;
     if (lkind == SOL_LEAF_REFS) {  // mixed node: the reference is listed
       const uint32_t r = ldg_u32(S.leaf_refs + idx);
@@ -505,7 +426,6 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
     if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
     return;
-#endif
   }
   uint32_t cur = t.cur;
   uint32_t kind = SOL_REF_KIND(cur);

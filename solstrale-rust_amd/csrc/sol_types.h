@@ -20,11 +20,6 @@
                             // MI355X, 1080p x 128 spp, C3 / C2 ms: 1: 199.8 / 128.4, 4: 196.6 / 126.5, 8: 193.1 / 122.5,
                             // 12: 193.0 / 122.6, 16: 199.1 / 129.7, 24: 215.7 / 148.0
 #endif
-#ifndef SOL_UNIFIED_STEP
-#define SOL_UNIFIED_STEP 0  // 1: trav_step fetches ONE record (node, triangle or sphere) per lane and step behind a single wait, instead
-                            // of node part + primitive part with a wait each. Measured slower (MI355X, 64 spp, ms 0 / 1: C1 11.7 / 14.3,
-                            // C2 55.1 / 61.8, C3 87.1 / 91.3): the primitives a node test finds must wait for the next step
-#endif
 #define SOL_CHUNK 16        // samples per work item; fixed so that summation order never depends on the partition
 #define SOL_TILE 8          // 8x8-pixel blocks = one wave's worth of adjacent work items
 #define SOL_POOL_MAX 1024   // path slots per wave in the pool kernel (u16 queue entries: 2 KiB of LDS per wave)
