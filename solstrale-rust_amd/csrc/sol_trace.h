@@ -254,7 +254,10 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
     const float tnz = fmaf((float)(((nzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az), tfz = fmaf((float)(((fzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az); \
     const float te = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));                                                         \
     const float tx = fminf(fminf(tfx, tfy), fminf(tfz, cull_t));                                                        \
-    hits |= (te <= tx) ? (1u << (i)) : 0u; /* an empty slot has an inverted box; at worst it yields a NONE ref (no-op) */ \
+    /* te <= tx as the sign of tx - te, shifted into the mask: a subtraction and one alignbit instead of compare, select and */ \
+    /* or. te is in [0, inf], tx in [-inf, FLT_MAX] (cull_t is finite), so the difference is never NaN; tx = -0 counts as a  */ \
+    /* miss, which it is for a search with tmin > 0. An empty slot has an inverted box: a miss.                             */ \
+    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tx - te), 31u);                                                \
   }
 // The slab tests of one fetched 7-wide node (h = origin + meta, qa / qb / qc = the six plane arrays) for the ray of search `t`:
 // the search's new node group and primitive group.
@@ -266,11 +269,11 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   const float scx = __uint_as_float(((meta & 31u) + wide_emin) << 23), scy = __uint_as_float((((meta >> 5) & 31u) + wide_emin) << 23);
   const float scz = __uint_as_float((((meta >> 10) & 31u) + wide_emin) << 23);
 #ifdef SOL_NO_TCULL
-  const float cull_t = __builtin_huge_valf();
+  const float cull_t = 3.402823466e38f;
 #else
-  const float cull_t = t.h.t;  // t >= tmin > 0 in a world search
+  const float cull_t = fminf(t.h.t, 3.402823466e38f);  // t >= tmin > 0 in a world search; finite (see SOL_WIDE_CHILD)
 #endif
-  uint32_t hits = 0u;
+  uint32_t miss = 0u;  // children are tested 6 .. 0, each shifting its bit in at the bottom: child i ends on bit i
   // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
   // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
   // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
@@ -284,13 +287,14 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   const uint32_t nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
   const uint32_t ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
   const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
-  SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-  SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-  SOL_WIDE_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-  SOL_WIDE_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-  SOL_WIDE_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, 0)
-  SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, 0)
   SOL_WIDE_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+  SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+  SOL_WIDE_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+  SOL_WIDE_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+  SOL_WIDE_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+  SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+  SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+  const uint32_t hits = ~miss;
   const uint32_t imask = (meta >> 15) & 0x7Fu, lmask = (meta >> 22) & 0x7Fu;
   // inner hits into visit order: bit p <- bit p ^ octant (three conditional butterfly stages)
   uint32_t ih = hits & imask;
