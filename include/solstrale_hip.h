@@ -229,6 +229,9 @@ int sol_scene_build_times(const SolScene* scene, double out[4]);
 #define SOL_OPT_MAX_BLOCKS_PER_CU 2   /* 0 = as many as fit; n >= 1 caps resident workgroups per CU (occupancy studies)  */
 #define SOL_OPT_KERNEL 3              /* 0 auto, 1 one-path-per-lane (product), 2 / 3 wavefront variants (A/B only)      */
 #define SOL_OPT_WORK_ORDER 4          /* 0: plain chunk-major order, 1: heavy-first order from the creation probe        */
+#define SOL_OPT_FINE_TAIL 5           /* quarters of a 16-sample item per resident lane that the END of a launch hands out one
+                                         sample at a time (shorter tail; images unchanged); 0 off, -1 (default) decided by the
+                                         creation probe                                                                      */
 int sol_scene_set_option(SolScene* scene, int option, int64_t value);
 
 /* Image-tile sharding for one-process-per-GPU runs (no reference analogue). The image is cut

@@ -93,6 +93,9 @@ struct SolScene {
   std::vector<uint32_t> block_cost;  // per 8x8 block (global index): rays of its longest item in the cost probe; empty: no ordering
   uint32_t* order_dev = nullptr; size_t order_cap = 0;  // DevScene::block_order of the current partition  // albedo / normal accumulators (sol_render_aux), same layout as acc
   float* partial = nullptr; size_t partial_floats = 0;
+  int fine_tail = -1;                // SOL_OPT_FINE_TAIL / SOL_FINE_TAIL: quarters of a whole item per resident lane that the end of a launch hands
+                                     // out sample by sample; 0: none; -1: by the creation probe's node visits per sample (fine_tail_auto)
+  int fine_tail_auto = 0;
   float* image = nullptr;  // W*H*3 scratch for sol_read / sol_resolve_image
   uint8_t* rgb8 = nullptr;
   double* bloom_a = nullptr; double* bloom_b = nullptr; double* bloom_w = nullptr; size_t bloom_w_cap = 0;  // sol_bloom scratch
@@ -754,6 +757,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   if (const char* mb = std::getenv("SOL_MAX_BPC")) s->max_bpc = std::max(0, std::atoi(mb));  // occupancy experiments
   if (const char* ps = std::getenv("SOL_POOL_SLOTS")) s->pool_slots_override = (uint32_t)std::atoi(ps);
   if (const char* ps = std::getenv("SOL_WF_SLOTS")) s->wf_slots = std::max(4096, std::atoi(ps));
+  if (const char* ps = std::getenv("SOL_FINE_TAIL")) s->fine_tail = std::max(-1, std::atoi(ps));
   if (const char* ps = std::getenv("SOL_WF_MIN_ITEMS")) s->wf_min_items = (uint32_t)std::max(0, std::atoi(ps));
   s->has_medium = d->n_mediums > 0;
   s->blocks_x = (d->width + SOL_TILE - 1) / SOL_TILE;
@@ -820,6 +824,13 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     if (rc == SOL_OK && hipMemcpy(s->block_cost.data(), cost_dev, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = SOL_EDEVICE;
     hipFree(cost_dev);
     if (rc != SOL_OK) return rc == SOL_EDEVICE ? fail(SOL_EDEVICE, "cost probe failed") : rc;
+    // The fine tail takes an item fetch per SAMPLE (a dependent load, three integer divisions: ~2 us): worth it where a sample
+    // is long. MI355X, 1080p x 64 spp, ms with 0 / 1 / 2 whole items per lane in the tail: C3 (38 node visits per sample) 76.5 /
+    // 75.5 / 74.4, C2 (22) 45.5 / 45.7 / 46.3, C1 (2) 10.5 / 11.2 / 11.8.
+    if (s->stats.samples > 0) {
+      const double vps = (double)s->stats.node_visits / (double)s->stats.samples;
+      s->fine_tail_auto = vps >= 30.0 ? 8 : 0;
+    }
     s->stats = SolStats{};
     if ((rc = sol_clear(s)) || (rc = rebuild_order(s))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -851,6 +862,10 @@ int sol_scene_set_option(SolScene* s, int option, int64_t value) {
     case SOL_OPT_KERNEL:
       if (value < 0 || value > 3) return fail(SOL_EINVAL, "SOL_OPT_KERNEL: 0..3");
       s->kernel_version = (int)value;
+      return SOL_OK;
+    case SOL_OPT_FINE_TAIL:
+      if (value < -1 || value > 64) return fail(SOL_EINVAL, "SOL_OPT_FINE_TAIL: -1 (by the probe), 0 (off) .. 64 quarters of an item per lane");
+      s->fine_tail = (int)value;
       return SOL_OK;
     case SOL_OPT_WORK_ORDER:
       s->order_enabled = value != 0;
@@ -982,17 +997,40 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
     s->spill_words = spill_words;
   }
   const size_t slots3 = (size_t)P.n_local_blocks * 64u * 3u;
-  if (P.n_chunks > 1) {
-    size_t need = slots3 * P.n_chunks;
+  // Fine tail (v1): the last pairs (block, chunk) of the work order - all of them in the last chunk, blocks the probe found light -
+  // are handed out one sample at a time: about one whole item per resident lane (SOL_FINE_TAIL quarters), so that single
+  // samples are still on offer while the slowest lanes finish their last whole item. Counted launches keep whole items
+  // (per-item ray counts).
+  P.n_coarse = P.n_items;
+  P.fine_count = n - (P.n_chunks - 1u) * SOL_CHUNK;
+  P.stage_at = P.n_items;  // (= n_chunks * slots: right behind the chunk sums)
+  size_t stage_floats = 0;
+  const int fine_tail = s->fine_tail >= 0 ? s->fine_tail : s->fine_tail_auto;
+  if (version == 1 && !count && fine_tail > 0) {
+    const uint32_t rest = P.n_local_blocks - std::min(P.n_local_blocks, s->S.n_first);
+    const uint32_t pairs = std::min<uint32_t>(rest, (uint32_t)(((uint64_t)fine_tail * (P.total_threads / 64u) + 3u) / 4u));
+    const uint64_t total = items - (uint64_t)pairs * 64u + (uint64_t)pairs * 64u * SOL_CHUNK;
+    if (pairs > 0 && total <= SOL_MAX_ITEMS && items + (uint64_t)pairs * 64u * SOL_CHUNK <= 0xFFFFFFFFull) {
+      stage_floats = (size_t)pairs * 64u * SOL_CHUNK * 3u;
+      P.n_coarse = (uint32_t)(items - (uint64_t)pairs * 64u);
+      P.n_items = (uint32_t)total;
+    }
+  }
+  // v1 writes every chunk sum into `partial` (also when the call has a single chunk); v2 / v3 add a single chunk straight
+  // into the accumulator
+  const bool via_partial = version == 1 || P.n_chunks > 1;
+  if (via_partial) {
+    size_t need = slots3 * P.n_chunks + stage_floats;
     if (need > s->partial_floats) {
       HIP_TRY(hipStreamSynchronize(s->stream));
       if (s->partial) hipFree(s->partial);
       s->partial = nullptr;
+      s->partial_floats = 0;
       HIP_TRY(hipMalloc((void**)&s->partial, need * sizeof(float)));
       s->partial_floats = need;
     }
     // padding pixels of edge blocks are never written: keep them zero
-    if ((s->S.width % SOL_TILE) || (s->S.height % SOL_TILE)) HIP_TRY(hipMemsetAsync(s->partial, 0, need * sizeof(float), s->stream));
+    if ((s->S.width % SOL_TILE) || (s->S.height % SOL_TILE)) HIP_TRY(hipMemsetAsync(s->partial, 0, slots3 * P.n_chunks * sizeof(float), s->stream));
   }
   HIP_TRY(hipMemsetAsync(s->work, 0, sizeof(uint32_t), s->stream));
   if (count) HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(DevCounters), s->stream));
@@ -1033,7 +1071,8 @@ static int render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, b
   if (s->timing) { HIP_TRY(hipEventRecord(s->ev_stop, s->stream)); s->timed_launches++; }
   s->last_grid = grid;
   s->last_version = version;
-  if (P.n_chunks > 1) HIP_TRY(sol_launch_resolve(s->acc, s->partial, (uint32_t)slots3, P.n_chunks, s->stream));
+  if (P.n_coarse != P.n_items) HIP_TRY(sol_launch_stage_resolve(s->dscene, P, s->partial, s->stream));
+  if (via_partial) HIP_TRY(sol_launch_resolve(s->acc, s->partial, (uint32_t)slots3, P.n_chunks, s->stream));
   if (count) {
     DevCounters c;
     HIP_TRY(hipMemcpyAsync(&c, s->counters, sizeof c, hipMemcpyDeviceToHost, s->stream));

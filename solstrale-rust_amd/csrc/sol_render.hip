@@ -56,7 +56,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
 
   bool have_item = false, alive = false, in_flight = false;
   Item it = {0, 0, 0, 0};
-  uint32_t s = 0, s_end = 0;
+  uint32_t s = 0, s_end = 0, out_at = 0;  // out_at: where the item's sum goes, in RGB triples from `partial`
   f3 sum = mk3(0.f, 0.f, 0.f);
   Path p = {};
   Trav t;
@@ -78,9 +78,12 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
           alive = false;
           s++;
           if (s == s_end) {
-            write_chunk(P, acc, partial, it.slot, it.chunk, sum);
-            have_item = false;
+            // the item's sum: a chunk sum for sol_resolve_kernel, or one sample of the fine tail for sol_stage_resolve_kernel -
+            // where it goes was worked out when the item was taken
+            float* a = partial + (size_t)out_at * 3;
+            a[0] = sum.x; a[1] = sum.y; a[2] = sum.z;
             if (COUNT && S.block_cost) atomicMax(S.block_cost + (it.slot >> 6), cnt.rays - item_rays0);  // the longest item decides
+            have_item = false;
           }
         }
       }
@@ -107,9 +110,21 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         }
         const uint32_t item = my < left ? next + my : fresh + (my - left);
         if (item >= P.n_items) break;  // no work left for this lane
-        if (!decode_item_ordered(S, P, item, it)) continue;
-        s = P.first_sample + it.chunk * SOL_CHUNK;
-        s_end = min(s + SOL_CHUNK, P.first_sample + P.n_samples);
+        // The fine tail: the last pairs of the work order are handed out sample by sample, so that the launch does not end with
+        // every lane inside a 16-sample item of its own (~2.5 ms on C3, 4 ms of a launch whatever its length) but inside a
+        // single sample. Which lane computes a sample does not change it; the samples are added up in order afterwards.
+        uint32_t citem = item, sub = 0u;
+        const bool fine = item >= P.n_coarse;
+        if (fine) {
+          const uint32_t f = item - P.n_coarse, g = f >> 6;
+          citem = P.n_coarse + ((g >> 4) << 6) + (f & 63u);
+          sub = g & 15u;
+          if (sub >= P.fine_count) continue;
+        }
+        if (!decode_item_ordered(S, P, citem, it)) continue;
+        s = P.first_sample + it.chunk * SOL_CHUNK + sub;
+        s_end = fine ? s + 1u : min(s + SOL_CHUNK, P.first_sample + P.n_samples);
+        out_at = fine ? P.stage_at + (citem - P.n_coarse) * SOL_CHUNK + sub : it.chunk * (P.n_local_blocks * 64u) + it.slot;
         sum = mk3(0.f, 0.f, 0.f);
         have_item = true;
         alive = false;
@@ -136,6 +151,28 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
     }
   }
   if (COUNT) flush_counters(cnt, dcnt);
+}
+
+// The fine tail's second half: one thread per (pair, pixel) of the tail adds the pair's samples in order - the sum a lane would
+// have formed had it taken the whole chunk - and writes it where that lane would have.
+__global__ void __launch_bounds__(256) sol_stage_resolve_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* __restrict__ partial) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= P.n_items - P.n_coarse) return;  // (the launcher passes n_items = n_coarse + pixels of the tail here)
+  Item it;
+  if (!decode_item_ordered(*Sp, P, P.n_coarse + i, it)) return;
+  f3 sum = mk3(0.f, 0.f, 0.f);
+  const float* a = partial + ((size_t)P.stage_at + (size_t)i * SOL_CHUNK) * 3;
+  for (uint32_t k = 0; k < P.fine_count; ++k) sum = sum + mk3(a[3 * k], a[3 * k + 1], a[3 * k + 2]);
+  float* o = partial + ((size_t)it.chunk * (P.n_local_blocks * 64u) + it.slot) * 3;
+  o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+}
+hipError_t sol_launch_stage_resolve(const DevScene* dS, const RenderParams& P, float* partial, hipStream_t stream) {
+  RenderParams Q = P;
+  const uint32_t pixels = (P.n_items - P.n_coarse) / SOL_CHUNK;
+  if (pixels == 0) return hipSuccess;
+  Q.n_items = P.n_coarse + pixels;
+  hipLaunchKernelGGL(sol_stage_resolve_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream, dS, Q, partial);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -37,6 +37,9 @@ struct Counters {
 // wave counts the 64 slots of this execution.
 template <bool COUNT>
 DEV void phase_tick(Counters& cnt, int ph) {
+#ifdef SOL_PROBE_STEP
+  return;  // (probe build: the six counters describe the two parts of a search step instead, see trav_step)
+#endif
   if (COUNT) {
     cnt.phase[2 * ph]++;
     const unsigned long long m = __ballot(1);
@@ -359,6 +362,19 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
   phase_tick<COUNT>(cnt, 0);
   if (!BINARY) {
     const uint32_t oct = t.oct;
+#ifdef SOL_PROBE_STEP
+    // probe build (tests/tools/variants.py, perf_quick --phases): [0] lanes in node parts, [1] 64 per node part executed by the
+    // wave, [2] / [3] the same for primitive parts, [4] lanes holding primitives while a node part runs, [5] of those, the
+    // lanes whose primitive part is then postponed
+    if (COUNT) {
+      const bool node_lane = (t.pg >> 24) == 0u;
+      const unsigned long long nm = __ballot(node_lane);
+      if (nm != 0ull) {
+        if (node_lane) cnt.phase[0]++; else cnt.phase[4]++;
+        if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt.phase[1] += 64u;
+      }
+    }
+#endif
     if ((t.pg >> 24) == 0u) {
       uint32_t g0 = t.g0, g1 = t.g1;
       if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
@@ -413,9 +429,18 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     // not depend on the order of the tests.
     const unsigned long long inner_m = __ballot(has_inner), prim_m = __ballot(has_prim);
     if (!has_prim) return;
+#ifdef SOL_PROBE_STEP
+    if (COUNT && inner_m != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) cnt.phase[5]++;
+#endif
     if (inner_m != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) return;
 #else
     if (!has_prim) return;
+#endif
+#ifdef SOL_PROBE_STEP
+    if (COUNT) {
+      cnt.phase[2]++;
+      if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt.phase[3] += 64u;
+    }
 #endif
     const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
     t.pg &= ~(1u << (24u + slot));

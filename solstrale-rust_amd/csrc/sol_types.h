@@ -196,6 +196,14 @@ struct RenderParams {
   uint32_t pool_slots;       // pool kernel: path slots per wave (multiple of 64, <= SOL_POOL_MAX)
   uint32_t switch_below;     // v1: a wave leaves the search loop for shading once fewer than this many of its live lanes
                              // (in 64ths) are still searching and some lane waits; 0 = search until every lane is done
+  // v1 writes every item's sum into the `partial` buffer: chunk sums at [chunk][slot], and behind them (from RGB triple stage_at)
+  // the sample colours of the fine tail. Items [0, n_coarse) are whole 16-sample chunks; the items from
+  // n_coarse on are the LAST pairs (block, chunk) of the work order handed out one sample at a time - item
+  // n_coarse + ((j * 16 + sub) * 64 + pin) is sample `sub` of pixel `pin` of pair n_coarse / 64 + j - and their colours go to triple
+  // stage_at + (j * 64 + pin) * 16 + sub, which sol_stage_resolve_kernel adds up in sample order. n_coarse == n_items: no fine tail.
+  uint32_t n_coarse;
+  uint32_t fine_count;       // samples of the last chunk (1 .. 16): fine items with sub >= fine_count do not exist
+  uint32_t stage_at;
 };
 
 struct DevCounters {

@@ -33,15 +33,44 @@ def test_scheduler_options_do_not_change_the_frame():
     with DeviceScene(sc) as ds:
         want = _frame(ds)
         for opt, values in ((_abi.OPT_SWITCH_BELOW, (0, 8, 40, 64)), (_abi.OPT_MAX_BLOCKS_PER_CU, (1, 2, 0)), (_abi.OPT_WORK_ORDER, (0, 1)),
-                            (_abi.OPT_KERNEL, (2, 3, 1, 0))):
+                            (_abi.OPT_FINE_TAIL, (0, 4, 64, -1)), (_abi.OPT_KERNEL, (2, 3, 1, 0))):
             for v in values:
                 ds.set_option(opt, v)
                 assert (_frame(ds) == want).all(), (opt, v)
-        for opt, v in ((_abi.OPT_SWITCH_BELOW, 65), (_abi.OPT_SWITCH_BELOW, -1), (_abi.OPT_KERNEL, 4), (99, 0)):
+        for opt, v in ((_abi.OPT_SWITCH_BELOW, 65), (_abi.OPT_SWITCH_BELOW, -1), (_abi.OPT_KERNEL, 4), (_abi.OPT_FINE_TAIL, -2), (_abi.OPT_FINE_TAIL, 65), (99, 0)):
             with pytest.raises(DeviceError) as e:
                 ds.set_option(opt, v)
             assert e.value.code == _abi.SOL_EINVAL
         assert (_frame(ds) == want).all()
+
+
+@pytest.mark.parametrize("size", [(240, 136), (250, 131)], ids=["whole_blocks", "edge_blocks"])
+def test_fine_tail_keeps_every_frame(size):
+    """SOL_OPT_FINE_TAIL: the last items of a launch are handed out one sample at a time and their colours added up in sample
+    order afterwards - the same sums, bit for bit, for every tail length, sample count (whole and ragged last chunks, one
+    chunk and many), sample offset, partition and accumulation over calls."""
+    sc = scenes.sponza_like(RenderConfig(size[0], size[1], 16))
+    with DeviceScene(sc) as ds:
+        def frames():
+            out = []
+            for spp in (5, 16, 37, 64):
+                out.append(_frame(ds, spp))
+            ds.clear()
+            ds.render(0, 20, pu.SEED)
+            ds.render(20, 17, pu.SEED)  # (accumulates on the first call's sums; chunks are counted from each call's first sample)
+            out.append(ds.read())
+            ds.set_partition(3, 8)
+            ds.clear()
+            ds.render(0, 37, pu.SEED)
+            out.append(ds.read())  # (this rank's tiles; the others stay zero)
+            ds.set_partition(0, 1)
+            return out
+        ds.set_option(_abi.OPT_FINE_TAIL, 0)
+        want = frames()
+        for tail in (1, 4, 16, 64):
+            ds.set_option(_abi.OPT_FINE_TAIL, tail)
+            for k, (a, b) in enumerate(zip(frames(), want)):
+                assert a.shape == b.shape and (a == b).all(), (tail, k)
 
 
 def test_creation_without_the_work_order_probe():
