@@ -15,7 +15,14 @@ import sys
 def main():
     root, kname, samples = sys.argv[1], sys.argv[2], float(sys.argv[3])
     counters, dur_ns = {}, []
-    for f in sorted(glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv"))):
+    # one file per counter group: the newest (gpurun merges every call's output into the same local directory, so a group
+    # directory can hold the passes of earlier calls too)
+    newest = {}
+    for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+        grp = os.path.relpath(f, root).split(os.sep)[0]
+        if grp not in newest or os.path.getmtime(f) > os.path.getmtime(newest[grp]):
+            newest[grp] = f
+    for f in sorted(newest.values()):
         seen = set()
         for row in csv.DictReader(open(f)):
             if kname not in row["Kernel_Name"]:
