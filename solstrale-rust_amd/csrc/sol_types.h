@@ -20,6 +20,9 @@
                             // MI355X, 1080p x 128 spp, C3 / C2 ms: 1: 199.8 / 128.4, 4: 196.6 / 126.5, 8: 193.1 / 122.5,
                             // 12: 193.0 / 122.6, 16: 199.1 / 129.7, 24: 215.7 / 148.0
 #endif
+#ifndef SOL_LEAF_KIND_DISPATCH
+#define SOL_LEAF_KIND_DISPATCH 1  // primitive part of trav_step: 0 every kind through prim_test's chain, 1 triangle leaves direct
+#endif
 #define SOL_CHUNK 16        // samples per work item; fixed so that summation order never depends on the partition
 #define SOL_TILE 8          // 8x8-pixel blocks = one wave's worth of adjacent work items
 #define SOL_POOL_MAX 1024   // path slots per wave in the pool kernel (u16 queue entries: 2 KiB of LDS per wave)
