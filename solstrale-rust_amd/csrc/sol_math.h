@@ -19,6 +19,10 @@
 // triangle then also drains the queue of the LDS traversal stack - and pays the aperture check. They are all global
 // (hipMalloc). Neither an address-space round trip nor an is_shared/is_private assumption survives to the backend; what does
 // is a load THROUGH an address-space-1 pointer, so every scene record is fetched with these helpers (global_load_dword*).
+// Lane mask of a condition. HIP's __ballot(int) compares a 0 / 1 VALUE with zero: when the condition is a lane mask already
+// (a compare result) the compiler materialises it with v_cndmask and compares again, two 4-cycle instructions per ballot in
+// the search loop; the builtin takes the condition as it is.
+#define sol_ballot(cond) __builtin_amdgcn_ballot_w64(cond)
 #define SOL_AS1 __attribute__((address_space(1)))
 typedef float sol_v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t sol_v4u __attribute__((ext_vector_type(4)));

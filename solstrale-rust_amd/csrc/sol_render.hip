@@ -92,7 +92,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
       // prefix. The wave thus waits for the global counter (1-3 us under load, ~88 dequeues/us per address) once per 64
       // items instead of once per service pass.
       if (!have_item) {
-        const unsigned long long need = __ballot(1);
+        const unsigned long long need = sol_ballot(true);
         const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
         const uint32_t n_need = (uint32_t)__popcll(need), my = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
         // volatile: the leader's stores and every lane's loads must stay real LDS accesses in program order (one wave's LDS
@@ -143,9 +143,9 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
     // its lanes are still searching while others wait (P.switch_below 64ths of the live lanes; 0: when none is searching).
     for (;;) {
       const bool act = t.cur != REF_DONE;
-      const unsigned long long am = __ballot(act);
+      const unsigned long long am = sol_ballot(act);
       if (am == 0ull) break;
-      const unsigned long long live = __ballot(1);
+      const unsigned long long live = sol_ballot(true);
       if (am != live && (uint32_t)__popcll(am) * 64u < P.switch_below * (uint32_t)__popcll(live)) break;
       if (act) trav_step<COUNT, MEDIUM, SOL_WORLD_BINARY>(S, t, st, p.rng, p.depth, cnt);
     }
@@ -233,7 +233,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
       float4 r1 = rec[1 * NS + sl];
       uint32_t flags = __float_as_uint(r1.w);
       // wave-uniform shortcut: nothing in these 64 slots and nothing left to fetch
-      if (exhausted && __ballot((flags & PF_ITEM) != 0) == 0ull) continue;
+      if (exhausted && sol_ballot((flags & PF_ITEM) != 0) == 0ull) continue;
       Path p = {};
       Item it = {0, 0, 0, 0};
       uint32_t s = 0;
@@ -269,7 +269,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
       }
       bool refused = false;
       if (!has_item && !exhausted) {  // take the next work item: one atomic for the wave, popcount prefix per lane
-        const unsigned long long need = __ballot(1);
+        const unsigned long long need = sol_ballot(true);
         const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
         uint32_t b0 = 0;
         if (lane == leader) b0 = atomicAdd(work_counter, (uint32_t)__popcll(need));
@@ -284,7 +284,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
         }
       }
       // the counter is monotone: once any lane was refused, every later fetch of this wave would be refused too
-      if (__ballot(refused) != 0ull) exhausted = true;
+      if (sol_ballot(refused) != 0ull) exhausted = true;
       if (has_item && !alive) {
         phase_tick<COUNT>(cnt, 2);
         generate_path<COUNT>(S, P.seed_lo, P.seed_hi, it.px, it.py, s, p, cnt);
@@ -304,7 +304,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
         rec[1 * NS + sl] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       // compaction: live rays of these 64 slots go to the queue in slot order
-      const unsigned long long live = __ballot(has_item);
+      const unsigned long long live = sol_ballot(has_item);
       if (has_item) queue[qn + (uint32_t)__popcll(live & lanes_below)] = (uint16_t)sl;
       qn += (uint32_t)__popcll(live);
     }
@@ -319,7 +319,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
     Rng rng_medium = {0, 0, 0};
     uint32_t depth_medium = 0;
     for (;;) {
-      const unsigned long long idle = __ballot(!have);
+      const unsigned long long idle = sol_ballot(!have);
       const uint32_t n_idle = (uint32_t)__popcll(idle);
       if (head < qn && (n_idle >= SOL_REFILL_MIN || n_idle == 64u)) {
         if (!have) {
@@ -339,7 +339,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
         }
         head = min(qn, head + n_idle);
       }
-      if (__ballot(have) == 0ull) break;  // every queued ray has been searched
+      if (sol_ballot(have) == 0ull) break;  // every queued ray has been searched
       if (have) {
         for (int k = 0; k < SOL_TRAV_BURST && t.cur != REF_DONE; ++k) trav_step<COUNT, MEDIUM, SOL_WORLD_BINARY>(S, t, st, rng_medium, depth_medium, cnt);
         if (t.cur == REF_DONE) {

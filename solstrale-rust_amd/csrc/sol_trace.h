@@ -42,7 +42,7 @@ DEV void phase_tick(Counters& cnt, int ph) {
 #endif
   if (COUNT) {
     cnt.phase[2 * ph]++;
-    const unsigned long long m = __ballot(1);
+    const unsigned long long m = sol_ballot(true);
     if ((int)__lane_id() == __ffsll((long long)m) - 1) cnt.phase[2 * ph + 1] += 64u;
   }
 }
@@ -386,10 +386,10 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     // lanes whose primitive part is then postponed
     if (COUNT) {
       const bool node_lane = (t.pg >> 24) == 0u;
-      const unsigned long long nm = __ballot(node_lane);
+      const unsigned long long nm = sol_ballot(node_lane);
       if (nm != 0ull) {
         if (node_lane) cnt.phase[0]++; else cnt.phase[4]++;
-        if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt.phase[1] += 64u;
+        if ((int)__lane_id() == __ffsll((long long)sol_ballot(true)) - 1) cnt.phase[1] += 64u;
       }
     }
 #endif
@@ -440,24 +440,25 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     // status for the callers' loops, and for the postponing rule below
     const bool has_prim = (t.pg >> 24) != 0u;
     const bool has_inner = !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);
-    if (!has_prim && !has_inner) { t.cur = REF_DONE; return; }
 #if SOL_PRIM_MIN > 1
     // Postponed primitive tests: the lanes holding primitives wait while fewer than SOL_PRIM_MIN of the wave's lanes do and
     // some lane still has an inner node to visit next turn; the primitive part then runs with more lanes enabled. Results do
     // not depend on the order of the tests.
-    const unsigned long long inner_m = __ballot(has_inner), prim_m = __ballot(has_prim);
+    const unsigned long long inner_m = sol_ballot(has_inner), prim_m = sol_ballot(has_prim);
+    if (!has_prim && !has_inner) { t.cur = REF_DONE; return; }
     if (!has_prim) return;
 #ifdef SOL_PROBE_STEP
     if (COUNT && inner_m != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) cnt.phase[5]++;
 #endif
     if (inner_m != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) return;
 #else
+    if (!has_prim && !has_inner) { t.cur = REF_DONE; return; }
     if (!has_prim) return;
 #endif
 #ifdef SOL_PROBE_STEP
     if (COUNT) {
       cnt.phase[2]++;
-      if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) cnt.phase[3] += 64u;
+      if ((int)__lane_id() == __ffsll((long long)sol_ballot(true)) - 1) cnt.phase[3] += 64u;
     }
 #endif
     const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
