@@ -100,6 +100,19 @@ DEV void stack_push(const Stack& s, int& sp, uint32_t v) {
   stack_store(s, sp, v);
   sp++;
 }
+// Pops one two-dword entry (pushed as `first`, then `second`): in a kernel without a spill area one address and one
+// ds_read2st64_b32 instead of two of each.
+DEV void stack_pop2(const Stack& s, int& sp, uint32_t& first, uint32_t& second) {
+  sp -= 2;
+  if (s.depth >= SOL_NO_SPILL) {
+    const lds_u32* p = s.lds + sp * SOL_WG;
+    first = p[0];
+    second = p[SOL_WG];
+  } else {
+    first = sp < s.depth ? s.lds[sp * SOL_WG] : s.spill[(size_t)(sp - s.depth) * s.stride];
+    second = sp + 1 < s.depth ? s.lds[(sp + 1) * SOL_WG] : s.spill[(size_t)(sp + 1 - s.depth) * s.stride];
+  }
+}
 DEV uint32_t stack_pop(const Stack& s, int& sp) {
   sp--;
   uint32_t v;
@@ -396,8 +409,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     if ((t.pg >> 24) == 0u) {
       uint32_t g0 = t.g0, g1 = t.g1;
       if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
-        g1 = stack_pop(st, t.sp);
-        g0 = stack_pop(st, t.sp);
+        stack_pop2(st, t.sp, g0, g1);
       }
       const uint32_t p = (uint32_t)__builtin_ctz(g0 >> 24);  // nearest: lowest bit in visit order
       const uint32_t slot = p ^ oct;
