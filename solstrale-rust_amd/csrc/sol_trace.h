@@ -263,13 +263,19 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
 // the ray direction. This is NOT the reference's (b - o) * inv sequence and need not be: the boxes are culls, and the
 // builder pads them by twice the fp32 box pad, three times the worst rounding error of this evaluation.
 // NaN (0 * inf for axis-parallel rays) is ignored by fmaxf / fminf, i.e. treated as "no constraint": conservative.
+// v_min_f32 as it is: fminf on a value the compiler cannot prove canonical (cull_t, built from bits) costs a v_max x, x first
+DEV float sol_min_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 #define SOL_WIDE_CHILD(i, nxw, nyw, nzw, fxw, fyw, fzw, refv)                                                          \
   {                                                                                                                     \
     const float tnx = fmaf((float)(((nxw) >> (8 * ((i) & 3))) & 0xFFu), bx, ax), tfx = fmaf((float)(((fxw) >> (8 * ((i) & 3))) & 0xFFu), bx, ax); \
     const float tny = fmaf((float)(((nyw) >> (8 * ((i) & 3))) & 0xFFu), by, ay), tfy = fmaf((float)(((fyw) >> (8 * ((i) & 3))) & 0xFFu), by, ay); \
     const float tnz = fmaf((float)(((nzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az), tfz = fmaf((float)(((fzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az); \
     const float te = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));                                                         \
-    const float tx = fminf(fminf(tfx, tfy), fminf(tfz, cull_t));                                                        \
+    const float tx = fminf(fminf(tfx, tfy), sol_min_raw(tfz, cull_t));                                                        \
     /* te <= tx as the sign of tx - te, shifted into the mask: a subtraction and one alignbit instead of compare, select and */ \
     /* or. te is in [0, inf], tx in [-inf, FLT_MAX] (cull_t is finite), so the difference is never NaN; tx = -0 counts as a  */ \
     /* miss, which it is for a search with tmin > 0. An empty slot has an inverted box: a miss.                             */ \
@@ -287,7 +293,9 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
 #ifdef SOL_NO_TCULL
   const float cull_t = 3.402823466e38f;
 #else
-  const float cull_t = fminf(t.h.t, 3.402823466e38f);  // t >= tmin > 0 in a world search; finite (see SOL_WIDE_CHILD)
+  // t >= tmin > 0 in a world search; made finite (see SOL_WIDE_CHILD) by an unsigned minimum of the bit patterns: best t is a
+  // positive float or +inf, never NaN, and one instruction where fminf takes two (canonicalise, then minimum)
+  const float cull_t = __uint_as_float(min(__float_as_uint(t.h.t), 0x7F7FFFFFu));
 #endif
   uint32_t miss = 0u;  // children are tested 6 .. 0, each shifting its bit in at the bottom: child i ends on bit i
   // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
@@ -414,7 +422,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       const uint32_t p = (uint32_t)__builtin_ctz(g0 >> 24);  // nearest: lowest bit in visit order
       const uint32_t slot = p ^ oct;
       g0 &= ~(1u << (24u + p));
-      const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc((g1 >> 15) & ((1u << slot) - 1u));  // rank among the node's inner children (imask)
+      const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(g1, 15u, slot));  // rank among the node's inner children: imask bits below `slot`
       if ((g0 >> 24) != 0u) {  // siblings left: one stack entry for all of them
         stack_push(st, t.sp, g0);
         stack_push(st, t.sp, g1);
@@ -476,7 +484,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
     t.pg &= ~(1u << (24u + slot));
     const uint32_t lkind = t.g1 >> 29;  // (no group was popped since this node's test: a lane with pending primitives skips part 1)
-    uint32_t idx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc((t.g1 >> 22) & ((1u << slot) - 1u));
+    uint32_t idx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(t.g1, 22u, slot));  // lmask bits below `slot`
     // Triangle leaves go straight to their test: through prim_test's chain (leaf kind -> reference kind -> compare tree) every
     // test had nine more vector instructions in front of it. MI355X, 64 spp, ms: C3 74.8 -> 73.3; a direct path for EVERY leaf
     // kind was no better (C3 73.8, C1 10.75 against 10.57 / 10.67): the other kinds keep the chain.
