@@ -32,6 +32,48 @@ __global__ void __launch_bounds__(256) gather(const v4u* table, unsigned n_piece
   out[blockIdx.x * 256u + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
 }
 
+// The same with 8-byte accesses (global_load_dwordx2) of every lane's own random 16-byte segment: what a node fetch split into
+// per-axis near / far halves would cost per instruction.
+__global__ void __launch_bounds__(256) gather_x2(const v4u* table, unsigned n_pieces_mask, int iters, unsigned* out) {
+  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+  const unsigned lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  unsigned state = wave * 9781u + lane * 6271u + 12345u;
+  v2u acc = {0, 0};
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      state = state * 1664525u + 1013904223u;
+      const unsigned seg = (state >> 8) & n_pieces_mask;
+      const v2u v = ((const AS1 v2u*)table)[2u * seg + ((state >> 7) & 1u)];
+      acc ^= v;
+    }
+  }
+  out[blockIdx.x * 256u + threadIdx.x] = acc.x ^ acc.y;
+}
+static void run_x2(const v4u* table, size_t bytes, const char* where, int wg_per_cu) {
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, 0);
+  const int n_cu = prop.multiProcessorCount, grid = n_cu * wg_per_cu, iters = 2000;
+  unsigned* out;
+  hipMalloc(&out, (size_t)grid * 256 * 4);
+  const unsigned mask = (unsigned)(bytes / 16 - 1);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(gather_x2, dim3(grid), dim3(256), 0, 0, table, mask, 50, out);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(gather_x2, dim3(grid), dim3(256), 0, 0, table, mask, iters, out);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double instr_per_cu = (double)wg_per_cu * 4 * iters * 8;
+  const double ns_per_instr = ms * 1e6 / instr_per_cu;
+  std::printf("%-14s dwordx2, every lane its own segment  waves/CU %2d  %7.3f ms  %6.1f ns per wave-load per CU (~%5.1f clk @2.1GHz)\n", where,
+              wg_per_cu * 4, ms, ns_per_instr, ns_per_instr * 2.1);
+  hipFree(out);
+}
+
 template <int GROUP>
 static void run(const v4u* table, size_t bytes, const char* where, int wg_per_cu) {
   hipDeviceProp_t prop;
@@ -71,6 +113,7 @@ int main() {
       run<8>(table, sizes[t], names[t], wg);
       run<16>(table, sizes[t], names[t], wg);
       run<64>(table, sizes[t], names[t], wg);
+      run_x2(table, sizes[t], names[t], wg);
     }
     hipFree(table);
   }
