@@ -49,11 +49,19 @@
 #define CVTF16(k) "v_cvt_f32_f16 %" #k ", %" #k "\n"
 #define ORB(k) "v_or_b32 %" #k ", %" #k ", %8\n"
 #define LSHL(k) "v_lshlrev_b32 %" #k ", 1, %" #k "\n"
+#define MULU24(k) "v_mul_u32_u24 %" #k ", %" #k ", %8\n"
+#define MADU24(k) "v_mad_u32_u24 %" #k ", %" #k ", %8, %9\n"
+#define ADD3(k) "v_add3_u32 %" #k ", %" #k ", %8, %9\n"
+#define LSHLADD(k) "v_lshl_add_u32 %" #k ", %" #k ", 2, %9\n"
+#define MINU(k) "v_min_u32 %" #k ", %" #k ", %8\n"
+#define FFBL(k) "v_ffbl_b32 %" #k ", %" #k "\n"
+#define LDEXP(k) "v_ldexp_f32 %" #k ", %" #k ", %8\n"
+#define BITOP3(k) "v_bitop3_b32 %" #k ", %" #k ", %8, %9 bitop3:0x30\n"
 #define SNOP(k) "s_nop 0\n"
 #define SMOV(k) "s_mov_b32 s20, s21\n"
 
-enum Op { kFma, kMul, kAdd, kMax, kMax3, kCvtUb, kCvtU, kAnd, kAddU, kLshlOr, kBfe, kPerm, kCndmask, kCmpVcc, kCmpS, kPkFma, kMov, kMed3, kRcp, kOr3, kBcnt, kMulLo, kSdwa, kSnop, kSmov, kCndS, kCndMix, kCndMix3, kAddc, kCmpAddc, kCmpCnd, kLshr, kXor, kSubF, kFmac, kFmaMix, kFmaMixLo, kAlignbit, kMin3, kCvtF16, kOr, kLshl, kOps };
-static const char* kNames[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_max_f32", "v_max3_f32", "v_cvt_f32_ubyte1", "v_cvt_f32_u32", "v_and_b32", "v_add_u32", "v_lshl_or_b32", "v_bfe_u32", "v_perm_b32", "v_cndmask_b32", "v_cmp_le_f32 vcc", "v_cmp_le_f32 sgpr", "v_pk_fma_f32", "v_mov_b32", "v_med3_f32", "v_rcp_f32", "v_or3_b32", "v_bcnt_u32_b32", "v_mul_lo_u32", "v_or_b32_sdwa", "s_nop 0", "s_mov_b32", "v_cndmask_b32 sgpr", "cndmask+fma (2 instr)", "cndmask+3fma (4 instr)", "v_addc_co_u32", "cmp+addc (2 instr)", "cmp+cndmask (2 instr)", "v_lshrrev_b32", "v_xor_b32", "v_sub_f32", "v_fmac_f32", "v_fma_mix_f32 (f16 hi)", "v_fma_mix_f32 (f16 lo)", "v_alignbit_b32", "v_min3_f32", "v_cvt_f32_f16", "v_or_b32", "v_lshlrev_b32"};
+enum Op { kFma, kMul, kAdd, kMax, kMax3, kCvtUb, kCvtU, kAnd, kAddU, kLshlOr, kBfe, kPerm, kCndmask, kCmpVcc, kCmpS, kPkFma, kMov, kMed3, kRcp, kOr3, kBcnt, kMulLo, kSdwa, kSnop, kSmov, kCndS, kCndMix, kCndMix3, kAddc, kCmpAddc, kCmpCnd, kLshr, kXor, kSubF, kFmac, kFmaMix, kFmaMixLo, kAlignbit, kMin3, kCvtF16, kOr, kLshl, kMulU24, kMadU24, kAdd3, kLshlAdd, kMinU, kFfbl, kLdexp, kBitop3, kOps };
+static const char* kNames[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_max_f32", "v_max3_f32", "v_cvt_f32_ubyte1", "v_cvt_f32_u32", "v_and_b32", "v_add_u32", "v_lshl_or_b32", "v_bfe_u32", "v_perm_b32", "v_cndmask_b32", "v_cmp_le_f32 vcc", "v_cmp_le_f32 sgpr", "v_pk_fma_f32", "v_mov_b32", "v_med3_f32", "v_rcp_f32", "v_or3_b32", "v_bcnt_u32_b32", "v_mul_lo_u32", "v_or_b32_sdwa", "s_nop 0", "s_mov_b32", "v_cndmask_b32 sgpr", "cndmask+fma (2 instr)", "cndmask+3fma (4 instr)", "v_addc_co_u32", "cmp+addc (2 instr)", "cmp+cndmask (2 instr)", "v_lshrrev_b32", "v_xor_b32", "v_sub_f32", "v_fmac_f32", "v_fma_mix_f32 (f16 hi)", "v_fma_mix_f32 (f16 lo)", "v_alignbit_b32", "v_min3_f32", "v_cvt_f32_f16", "v_or_b32", "v_lshlrev_b32", "v_mul_u32_u24", "v_mad_u32_u24", "v_add3_u32", "v_lshl_add_u32", "v_min_u32", "v_ffbl_b32", "v_ldexp_f32", "v_bitop3_b32"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) op_loop(float* out, int iters) {
@@ -113,10 +121,56 @@ __global__ void __launch_bounds__(256) op_loop(float* out, int iters) {
       if (OP == kCvtF16) asm volatile(REP8(CVTF16) OPERANDS);
       if (OP == kOr) asm volatile(REP8(ORB) OPERANDS);
       if (OP == kLshl) asm volatile(REP8(LSHL) OPERANDS);
+      if (OP == kMulU24) asm volatile(REP8(MULU24) OPERANDS);
+      if (OP == kMadU24) asm volatile(REP8(MADU24) OPERANDS);
+      if (OP == kAdd3) asm volatile(REP8(ADD3) OPERANDS);
+      if (OP == kLshlAdd) asm volatile(REP8(LSHLADD) OPERANDS);
+      if (OP == kMinU) asm volatile(REP8(MINU) OPERANDS);
+      if (OP == kFfbl) asm volatile(REP8(FFBL) OPERANDS);
+      if (OP == kLdexp) asm volatile(REP8(LDEXP) OPERANDS);
+      if (OP == kBitop3) asm volatile(REP8(BITOP3) OPERANDS);
       if (OP == kSmov) asm volatile(REP8(SMOV) OPERANDS : "s20");
     }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+// 64-bit address arithmetic (register pairs)
+template <int WHICH>
+__global__ void __launch_bounds__(256) op64_loop(unsigned long long* out, int iters) {
+  unsigned long long a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  unsigned long long b = 48;
+  unsigned int c = 7;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#define L64(k) "v_lshl_add_u64 %" #k ", %" #k ", 0, %8\n"
+#define M64(k) "v_mad_u64_u32 %" #k ", s[20:21], %9, 48, %" #k "\n"
+      if (WHICH == 0) asm volatile(REP8(L64) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+      if (WHICH == 1) asm volatile(REP8(M64) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s20", "s21");
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+template <int WHICH>
+static double run64(int wg_per_cu) {
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, 0);
+  const int n_cu = prop.multiProcessorCount, iters = 8000, grid = n_cu * wg_per_cu, threads = 256;
+  unsigned long long* out;
+  hipMalloc(&out, (size_t)grid * threads * 8);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(op64_loop<WHICH>, dim3(grid), dim3(threads), 0, 0, out, 100);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(op64_loop<WHICH>, dim3(grid), dim3(threads), 0, 0, out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipFree(out);
+  return (double)wg_per_cu * iters * 64.0 / (ms * 1e6);
 }
 
 template <int OP>
@@ -151,5 +205,7 @@ static void all(double* fma) {
 int main() {
   double fma[2] = {1, 1};
   all<0>(fma);
+  std::printf("%-20s 4 waves/SIMD %6.3f G/s/SIMD   8 waves/SIMD %6.3f G/s/SIMD\n", "v_lshl_add_u64", run64<0>(4), run64<0>(8));
+  std::printf("%-20s 4 waves/SIMD %6.3f G/s/SIMD   8 waves/SIMD %6.3f G/s/SIMD\n", "v_mad_u64_u32", run64<1>(4), run64<1>(8));
   return 0;
 }
