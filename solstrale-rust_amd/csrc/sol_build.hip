@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64) k_emit(EmitParams P, const Frontier* __res
   float lo[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()}, hi[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
   for (int c = 0; c < nc; ++c) {
     const float* b = P.nbox + (size_t)child[c] * 6;
-    for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], b[2 * a] - pad); hi[a] = fmaxf(hi[a], b[2 * a + 1] + pad); }
+    for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], b[2 * a] - 2.0f * pad); hi[a] = fmaxf(hi[a], b[2 * a + 1] + 2.0f * pad); }
   }
   uint32_t eb[3];
   float scale[3];
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(64) k_emit(EmitParams P, const Frontier* __res
     if (child[c] >= P.n_leaves) imask |= 1u << s; else lmask |= 1u << s;
     const float* b = P.nbox + (size_t)child[c] * 6;
     for (int a = 0; a < 3; ++a) {
-      const float cl = b[2 * a] - pad, chh = b[2 * a + 1] + pad;  // one more pad: the device evaluates the planes in t-space
+      const float cl = b[2 * a] - 2.0f * pad, chh = b[2 * a + 1] + 2.0f * pad;  // two more pads: the device evaluates the planes in t-space (sol_tree.h)
       long ql = (long)floorf((cl - lo[a]) / scale[a]), qh = (long)ceilf((chh - lo[a]) / scale[a]);
       ql = min(255L, max(0L, ql));
       qh = min(255L, max(0L, qh));

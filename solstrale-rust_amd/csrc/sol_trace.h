@@ -269,6 +269,23 @@ DEV float sol_min_raw(float a, float b) {
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+#if SOL_HALF_PLANES
+// Plane bytes become floats two at a time: v_perm_b32 puts two bytes of a plane word under the fp16 exponent of 1024 - the halves
+// (1024 + q0, 1024 + q1), exact - and v_fma_mix_f32 takes a half as its first factor: t = (1024 + q) * B + (A - 1024 * B). 24 + 42
+// vector instructions per node instead of 42 conversions + 42 FMAs, and the kernel's time follows its vector instruction count
+// (DESIGN.md 3). The shifted addend costs one more rounding, |A - 1024 B| * 2^-24: the builder's extra pad covers it (sol_tree.h).
+typedef _Float16 sol_h2 __attribute__((ext_vector_type(2)));
+#define SOL_H2(w, sel) __builtin_bit_cast(sol_h2, __builtin_amdgcn_perm(0x64646464u, (w), (sel)))
+#define SOL_WIDE_CHILD(i, hnx, hny, hnz, hfx, hfy, hfz, e)                                                             \
+  {                                                                                                                     \
+    const float tnx = fmaf((float)hnx.e, bx, ax), tfx = fmaf((float)hfx.e, bx, ax);                                     \
+    const float tny = fmaf((float)hny.e, by, ay), tfy = fmaf((float)hfy.e, by, ay);                                     \
+    const float tnz = fmaf((float)hnz.e, bz, az), tfz = fmaf((float)hfz.e, bz, az);                                     \
+    const float te = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));                                                         \
+    const float tx = fminf(fminf(tfx, tfy), sol_min_raw(tfz, cull_t));                                                  \
+    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tx - te), 31u);                                              \
+  }
+#else
 #define SOL_WIDE_CHILD(i, nxw, nyw, nzw, fxw, fyw, fzw, refv)                                                          \
   {                                                                                                                     \
     const float tnx = fmaf((float)(((nxw) >> (8 * ((i) & 3))) & 0xFFu), bx, ax), tfx = fmaf((float)(((fxw) >> (8 * ((i) & 3))) & 0xFFu), bx, ax); \
@@ -281,6 +298,7 @@ DEV float sol_min_raw(float a, float b) {
     /* miss, which it is for a search with tmin > 0. An empty slot has an inverted box: a miss.                             */ \
     miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tx - te), 31u);                                                \
   }
+#endif
 // The slab tests of one fetched 7-wide node (h = origin + meta, qa / qb / qc = the six plane arrays) for the ray of search `t`:
 // the search's new node group and primitive group.
 template <bool COUNT>
@@ -311,6 +329,25 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   const uint32_t nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
   const uint32_t ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
   const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
+#if SOL_HALF_PLANES
+  {
+    const float ax0 = ax, ay0 = ay, az0 = az;
+    const float ax = fmaf(-1024.0f, bx, ax0), ay = fmaf(-1024.0f, by, ay0), az = fmaf(-1024.0f, bz, az0);  // (shadow the plain addends)
+    const sol_h2 hnx01 = SOL_H2(nx0, 0x04010400u), hnx23 = SOL_H2(nx0, 0x04030402u), hnx45 = SOL_H2(nx1, 0x04010400u), hnx6 = SOL_H2(nx1, 0x04030402u);
+    const sol_h2 hny01 = SOL_H2(ny0, 0x04010400u), hny23 = SOL_H2(ny0, 0x04030402u), hny45 = SOL_H2(ny1, 0x04010400u), hny6 = SOL_H2(ny1, 0x04030402u);
+    const sol_h2 hnz01 = SOL_H2(nz0, 0x04010400u), hnz23 = SOL_H2(nz0, 0x04030402u), hnz45 = SOL_H2(nz1, 0x04010400u), hnz6 = SOL_H2(nz1, 0x04030402u);
+    const sol_h2 hfx01 = SOL_H2(fx0, 0x04010400u), hfx23 = SOL_H2(fx0, 0x04030402u), hfx45 = SOL_H2(fx1, 0x04010400u), hfx6 = SOL_H2(fx1, 0x04030402u);
+    const sol_h2 hfy01 = SOL_H2(fy0, 0x04010400u), hfy23 = SOL_H2(fy0, 0x04030402u), hfy45 = SOL_H2(fy1, 0x04010400u), hfy6 = SOL_H2(fy1, 0x04030402u);
+    const sol_h2 hfz01 = SOL_H2(fz0, 0x04010400u), hfz23 = SOL_H2(fz0, 0x04030402u), hfz45 = SOL_H2(fz1, 0x04010400u), hfz6 = SOL_H2(fz1, 0x04030402u);
+    SOL_WIDE_CHILD(6, hnx6, hny6, hnz6, hfx6, hfy6, hfz6, x)
+    SOL_WIDE_CHILD(5, hnx45, hny45, hnz45, hfx45, hfy45, hfz45, y)
+    SOL_WIDE_CHILD(4, hnx45, hny45, hnz45, hfx45, hfy45, hfz45, x)
+    SOL_WIDE_CHILD(3, hnx23, hny23, hnz23, hfx23, hfy23, hfz23, y)
+    SOL_WIDE_CHILD(2, hnx23, hny23, hnz23, hfx23, hfy23, hfz23, x)
+    SOL_WIDE_CHILD(1, hnx01, hny01, hnz01, hfx01, hfy01, hfz01, y)
+    SOL_WIDE_CHILD(0, hnx01, hny01, hnz01, hfx01, hfy01, hfz01, x)
+  }
+#else
   SOL_WIDE_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, 0)
   SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, 0)
   SOL_WIDE_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, 0)
@@ -318,6 +355,7 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   SOL_WIDE_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, 0)
   SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 0)
   SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+#endif
   const uint32_t hits = ~miss;
   const uint32_t imask = (meta >> 15) & 0x7Fu, lmask = (meta >> 22) & 0x7Fu;
   // inner hits into visit order: bit p <- bit p ^ octant (three conditional butterfly stages)

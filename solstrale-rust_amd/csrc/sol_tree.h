@@ -296,8 +296,8 @@ struct WideBuilder {
     float lo[3] = {F_INF, F_INF, F_INF}, hi[3] = {-F_INF, -F_INF, -F_INF};
     for (auto& ch : c)
       for (int a = 0; a < 3; ++a) {
-        if (std::isfinite(ch.box.v[2 * a])) lo[a] = std::min(lo[a], ch.box.v[2 * a] - pad);
-        if (std::isfinite(ch.box.v[2 * a + 1])) hi[a] = std::max(hi[a], ch.box.v[2 * a + 1] + pad);
+        if (std::isfinite(ch.box.v[2 * a])) lo[a] = std::min(lo[a], ch.box.v[2 * a] - 2.0f * pad);  // (the planes' two extra pads, below)
+        if (std::isfinite(ch.box.v[2 * a + 1])) hi[a] = std::max(hi[a], ch.box.v[2 * a + 1] + 2.0f * pad);
       }
     uint32_t eb[3];
     float scale[3];
@@ -389,9 +389,10 @@ struct WideBuilder {
     for (size_t i = 0; i < c.size(); ++i) {
       const int s = slot_of[i];
       for (int a = 0; a < 3; ++a) {
-        // one more box pad on top of the padded fp32 box: the device evaluates these planes in t-space (A + q * B), whose
-        // rounding error is up to ~0.7 pad; with the extra pad the margin is 3x
-        float cl = c[i].box.v[2 * a] - pad, chh = c[i].box.v[2 * a + 1] + pad;
+        // two more box pads on top of the padded fp32 box: the device evaluates these planes in t-space, t = (1024 + q) * B +
+        // (A - 1024 * B) (sol_trace.h), whose rounding error is up to ~1.1 pad at the root (|A| 2^-23 + |t| 2^-24 + |A - 1024 B|
+        // 2^-24, in units of the pad S 2^-20); with three pads between the plane and the primitive the margin is 2.7x
+        float cl = c[i].box.v[2 * a] - 2.0f * pad, chh = c[i].box.v[2 * a + 1] + 2.0f * pad;
         if (!std::isfinite(cl)) cl = lo[a];
         if (!std::isfinite(chh)) chh = hi[a];
         long ql = (long)std::floor((cl - lo[a]) / scale[a]);

@@ -20,6 +20,9 @@
                             // MI355X, 1080p x 128 spp, C3 / C2 ms: 1: 199.8 / 128.4, 4: 196.6 / 126.5, 8: 193.1 / 122.5,
                             // 12: 193.0 / 122.6, 16: 199.1 / 129.7, 24: 215.7 / 148.0
 #endif
+#ifndef SOL_HALF_PLANES
+#define SOL_HALF_PLANES 1
+#endif
 #ifndef SOL_LEAF_KIND_DISPATCH
 #define SOL_LEAF_KIND_DISPATCH 1  // primitive part of trav_step: 0 every kind through prim_test's chain, 1 triangle leaves direct
 #endif
