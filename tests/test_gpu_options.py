@@ -44,12 +44,13 @@ def test_scheduler_options_do_not_change_the_frame():
         assert (_frame(ds) == want).all()
 
 
+@pytest.mark.parametrize("make", [scenes.sponza_like, scenes.create_test_scene], ids=["c3", "test_scene_with_medium"])
 @pytest.mark.parametrize("size", [(240, 136), (250, 131)], ids=["whole_blocks", "edge_blocks"])
-def test_fine_tail_keeps_every_frame(size):
+def test_fine_tail_keeps_every_frame(size, make):
     """SOL_OPT_FINE_TAIL: the last items of a launch are handed out one sample at a time and their colours added up in sample
     order afterwards - the same sums, bit for bit, for every tail length, sample count (whole and ragged last chunks, one
     chunk and many), sample offset, partition and accumulation over calls."""
-    sc = scenes.sponza_like(RenderConfig(size[0], size[1], 16))
+    sc = make(RenderConfig(size[0], size[1], 16))
     with DeviceScene(sc) as ds:
         def frames():
             out = []
