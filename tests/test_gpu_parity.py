@@ -334,6 +334,13 @@ def test_deep_medium_boundary_uses_the_spill_stack():
         ds.render(0, 4, pu.SEED, counted=True)
         img = ds.read()
         st = ds.stats()
+        # the uncounted kernel variant (spill stack + medium), without and with the fine tail: the same frame as the counted one
+        from solstrale_amd import _abi
+        for tail in (0, 4):
+            ds.set_option(_abi.OPT_FINE_TAIL, tail)
+            ds.clear()
+            ds.render(0, 4, pu.SEED)
+            assert (ds.read() == img).all(), tail
     ref, _ = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F32)
     assert pu.compare(img, ref, 4)["bad_pixels"] == 0
     assert st["max_stack"] > 32, st  # the spill area was really used
