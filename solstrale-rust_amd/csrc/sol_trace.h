@@ -380,7 +380,13 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
 template <bool COUNT>
 DEV void triangle_prim_test(Trav& t, const Stack& st, uint32_t idx, Counters& cnt) {
   const float4* tp = reinterpret_cast<const float4*>(st.tris + idx);
+#if SOL_FETCH_PRIO >= 10
+  __builtin_amdgcn_s_setprio(SOL_FETCH_PRIO - 10);
+#endif
   const float4 p0 = ldg_f4(tp), p1 = ldg_f4(tp + 1), p2 = ldg_f4(tp + 2);
+#if SOL_FETCH_PRIO >= 10
+  asm volatile("s_setprio 0" ::: "memory");
+#endif
   DTri T;
   T.v0x = p0.x; T.v0y = p0.y; T.v0z = p0.z; T.e1x = p0.w; T.e1y = p1.x; T.e1z = p1.y; T.e2x = p1.z; T.e2y = p1.w; T.e2z = p2.x;
   const uint32_t dfs = __float_as_uint(p2.y);
@@ -453,6 +459,9 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     }
 #endif
     if ((t.pg >> 24) == 0u) {
+#if SOL_FETCH_PRIO
+      __builtin_amdgcn_s_setprio(SOL_FETCH_PRIO % 10);  // the wave about to fetch goes first: its memory latency starts now
+#endif
       uint32_t g0 = t.g0, g1 = t.g1;
       if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
         stack_pop2(st, t.sp, g0, g1);
@@ -469,6 +478,9 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       const float4* wp = reinterpret_cast<const float4*>(st.wides + idx);
       const float4 h = ldg_f4(wp);
       const uint4 qa = ldg_u4(wp + 1), qb = ldg_u4(wp + 2), qc = ldg_u4(wp + 3);
+#if SOL_FETCH_PRIO
+      asm volatile("s_setprio 0" ::: "memory");  // (after the loads are issued; asm: the builtin may be moved across them)
+#endif
       if (COUNT) cnt.node_visits++;
 #if defined(SOL_EXP_VMEM) || defined(SOL_EXP_VALU) || defined(SOL_EXP_LDS)
       // Sensitivity probes (A/B builds only, tests/tools/variants.py): extra work per node visit that changes no result -
