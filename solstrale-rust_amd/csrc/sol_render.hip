@@ -141,6 +141,9 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
     }
     // ---- search: one step per turn for every lane that has one. The wave leaves for the shading block when too few of
     // its lanes are still searching while others wait (P.switch_below 64ths of the live lanes; 0: when none is searching).
+#if SOL_LOOP_PRIO
+    __builtin_amdgcn_s_setprio(SOL_LOOP_PRIO);
+#endif
     for (;;) {
       const bool act = t.cur != REF_DONE;
       const unsigned long long am = sol_ballot(act);
@@ -149,6 +152,9 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
       if (am != live && (uint32_t)__popcll(am) * 64u < P.switch_below * (uint32_t)__popcll(live)) break;
       if (act) trav_step<COUNT, MEDIUM, SOL_WORLD_BINARY>(S, t, st, p.rng, p.depth, cnt);
     }
+#if SOL_LOOP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
   if (COUNT) flush_counters(cnt, dcnt);
 }

@@ -385,7 +385,7 @@ DEV void triangle_prim_test(Trav& t, const Stack& st, uint32_t idx, Counters& cn
 #endif
   const float4 p0 = ldg_f4(tp), p1 = ldg_f4(tp + 1), p2 = ldg_f4(tp + 2);
 #if SOL_FETCH_PRIO >= 10
-  asm volatile("s_setprio 0" ::: "memory");
+  asm volatile("s_setprio %0" ::"n"(SOL_LOOP_PRIO) : "memory");
 #endif
   DTri T;
   T.v0x = p0.x; T.v0y = p0.y; T.v0z = p0.z; T.e1x = p0.w; T.e1y = p1.x; T.e1z = p1.y; T.e2x = p1.z; T.e2y = p1.w; T.e2z = p2.x;
@@ -479,7 +479,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       const float4 h = ldg_f4(wp);
       const uint4 qa = ldg_u4(wp + 1), qb = ldg_u4(wp + 2), qc = ldg_u4(wp + 3);
 #if SOL_FETCH_PRIO
-      asm volatile("s_setprio 0" ::: "memory");  // (after the loads are issued; asm: the builtin may be moved across them)
+      asm volatile("s_setprio %0" ::"n"(SOL_LOOP_PRIO) : "memory");  // (after the loads are issued; asm: the builtin may be moved across them)
 #endif
       if (COUNT) cnt.node_visits++;
 #if defined(SOL_EXP_VMEM) || defined(SOL_EXP_VALU) || defined(SOL_EXP_LDS)

@@ -24,9 +24,13 @@
 #define SOL_HALF_PLANES 1
 #endif
 #ifndef SOL_FETCH_PRIO
-#define SOL_FETCH_PRIO 11        // s_setprio around the loads of a search step (units: node fetch, tens: + triangle fetch; 0 off): the wave
-                                 // about to fetch issues its addresses and loads ahead of the waves in their arithmetic.
-                                 // MI355X, 64 spp, ms 0 / 1 / 11: C3 70.6 / 70.2 / 70.0, C2 44.6 / 44.2 / 44.3
+#define SOL_FETCH_PRIO 33        // s_setprio around the loads of a search step (units: node fetch, tens: triangle fetch; 0 off): the wave
+                                 // about to fetch issues its addresses and loads ahead of the waves in their arithmetic
+#endif
+#ifndef SOL_LOOP_PRIO
+#define SOL_LOOP_PRIO 1          // priority of a wave inside the search loop (the service block runs at 0): a search is a chain of
+                                 // dependent fetches, shading is throughput work. MI355X, 64 spp, ms with (loop, fetch) = (0, 0) /
+                                 // (0, 1) / (1, 3): C3 70.6 / 70.0 / 69.4, C2 44.6 / 44.3 / 43.8, C1 10.56 / - / 10.39
 #endif
 #ifndef SOL_LEAF_KIND_DISPATCH
 #define SOL_LEAF_KIND_DISPATCH 1  // primitive part of trav_step: 0 every kind through prim_test's chain, 1 triangle leaves direct
