@@ -381,7 +381,7 @@ template <bool COUNT>
 DEV void triangle_prim_test(Trav& t, const Stack& st, uint32_t idx, Counters& cnt) {
   const float4* tp = reinterpret_cast<const float4*>(st.tris + idx);
 #if SOL_FETCH_PRIO >= 10
-  __builtin_amdgcn_s_setprio(SOL_FETCH_PRIO - 10);
+  __builtin_amdgcn_s_setprio(SOL_FETCH_PRIO / 10);
 #endif
   const float4 p0 = ldg_f4(tp), p1 = ldg_f4(tp + 1), p2 = ldg_f4(tp + 2);
 #if SOL_FETCH_PRIO >= 10

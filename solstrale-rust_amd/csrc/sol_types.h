@@ -30,7 +30,8 @@
 #ifndef SOL_LOOP_PRIO
 #define SOL_LOOP_PRIO 1          // priority of a wave inside the search loop (the service block runs at 0): a search is a chain of
                                  // dependent fetches, shading is throughput work. MI355X, 64 spp, ms with (loop, fetch) = (0, 0) /
-                                 // (0, 1) / (1, 3): C3 70.6 / 70.0 / 69.4, C2 44.6 / 44.3 / 43.8, C1 10.56 / - / 10.39
+                                 // (0, 1) / (1, 3): C3 70.6 / 70.0 / 69.4, C2 44.6 / 44.3 / 43.8, C1 10.56 / - / 10.39; the service block at 1 or 2 as
+                                 // well: C3 70.3 (slower)
 #endif
 #ifndef SOL_LEAF_KIND_DISPATCH
 #define SOL_LEAF_KIND_DISPATCH 1  // primitive part of trav_step: 0 every kind through prim_test's chain, 1 triangle leaves direct
