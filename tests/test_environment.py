@@ -57,7 +57,7 @@ def test_environment_parity_with_the_oracle():
         img = ds.read()
     ref, _ = orc.render(sc, 0, 16, pu.SEED, real=orc.ORC_F32)
     res = pu.compare(img, ref, 16)
-    assert res["bad_pixels"] <= 2 and res["max_rel"] <= pu.REL_TOL, res
+    assert res["bad_pixels"] == 0 and res["max_rel"] <= pu.REL_TOL, res  # (tests/tools/env_probe.py prints the paths of a pixel that differs)
     plain = scenes.create_test_scene(RenderConfig(200, 100, 16, PathTracingShader(50)))
     with DeviceScene(plain) as ds:
         ds.render(0, 16, pu.SEED)

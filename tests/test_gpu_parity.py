@@ -161,6 +161,18 @@ def test_c5_statue_class_crop():
     assert_parity(sc, 8, rect=(900, 60, 1028, 188))     # glass head (x 830-1020, y 55-255) against the background
 
 
+def test_c5_statue_hdri_crop():
+    """configs[4] AS BASELINE.json NAMES IT - "+ HDRI env light": the statue stand-in under the procedural HDR environment map
+    (EXTENSION, SolSceneDesc::env_*: the reference's miss branch src/renderer/mod.rs:197-204 returns a constant; the direction ->
+    texel mapping is calculate_sphere_uv, sphere.rs:134-140). Glass and metal paths ending on environment texels at 1.09 M
+    triangles; the two crops of test_c5_statue_class_crop plus one of the glass orb."""
+    sc = scenes.statue_like(RenderConfig(1920, 1080, 16), environment=True)
+    assert sc.desc.env_width > 0 and abs(sc.desc.n_triangles - scenes.STATUE_TRIANGLES) < 2000
+    assert_parity(sc, 16, rect=(896, 476, 1024, 604))   # body + drapery (metal: reflections of the sky)
+    assert_parity(sc, 8, rect=(900, 60, 1028, 188))     # glass head: refracted sky texels
+    assert_parity(sc, 8, rect=(1150, 860, 1278, 988))   # the glass orb (centre 1214,990, radius 146 px): sky through glass, floor around it
+
+
 def _atrium_with_bsdfs(rc):
     b = SceneBuilder()
     mats = [b.Lambertian(b.SolidColor(.7, .6, .5)), b.Lambertian(b.SolidColor(.3, .5, .7))]
