@@ -184,7 +184,7 @@ typedef struct SolSceneDesc {
 typedef struct SolStats {
   uint64_t samples;       /* ray_color(primary,0,0) evaluations                                         */
   uint64_t rays;          /* world closest-hit queries (src/renderer/mod.rs:165), any depth             */
-  uint64_t node_visits;   /* device BVH nodes fetched (sol_record_sizes: 96-B 8-wide nodes of the world)  */
+  uint64_t node_visits;   /* device BVH nodes fetched (sol_record_sizes: 64-B 7-wide nodes of the world)  */
   uint64_t sphere_tests, quad_tests, triangle_tests; /* primitive hit evaluations incl. light pdf tests */
   uint64_t shades;        /* material scatter evaluations                                               */
   uint64_t texel_fetches;
@@ -207,7 +207,8 @@ void sol_scene_destroy(SolScene* scene);
 
 /* Creation options (no reference analogue: the reference has one BVH builder and no scheduler to tune). All-zero = the
  * defaults of sol_scene_create. The SOL_* environment variables of DESIGN.md 9 remain developer overrides, read once here. */
-#define SOL_TREE_AUTO 0    /* the default: today the GPU build (SOL_TREE_DEVICE)                                      */
+#define SOL_TREE_AUTO 0    /* the default: the GPU build (SOL_TREE_DEVICE); when that fails - a primitive with a non-finite box,
+                              more than 2^23 primitives, no scratch memory - the host candidates + probe (SolSceneInfo says so) */
 #define SOL_TREE_REF 1     /* the reference's topology (src/hittable/bvh.rs:84-162), collapsed 8-wide                 */
 #define SOL_TREE_SAH8 2    /* host binned-SAH rebuild, 8 / 16 / 64 bins                                              */
 #define SOL_TREE_SAH16 3
@@ -223,6 +224,18 @@ typedef struct SolCreateOptions {
 int sol_scene_create_ex(const SolSceneDesc* desc, int device, const SolCreateOptions* options, SolScene** out);
 /* Seconds sol_scene_create spent in: [0] host tree candidates, [1] uploads, [2] device tree build, [3] probe renders. */
 int sol_scene_build_times(const SolScene* scene, double out[4]);
+
+/* What sol_scene_create decided (diagnostic; no reference analogue). stack_bound: the host's bound on the traversal stack use of
+ * any search of this scene, in dwords (2 per level of the 7-wide tree + the deepest medium boundary + 2): SolStats.max_stack of
+ * a counted render never exceeds it, and the kernel built without a spill path is launched only when it is <= lds_stack. */
+typedef struct SolSceneInfo {
+  uint32_t size;            /* in: sizeof(SolSceneInfo)                                                               */
+  uint32_t stack_bound, lds_stack, spill_stack;
+  uint32_t tree_fallback;   /* 1: SOL_TREE_AUTO's device build failed and the host candidates were used (tree_note)    */
+  char tree_name[32];       /* "device", "ref", "sah8", "sah16", "sah64"                                               */
+  char tree_note[192];
+} SolSceneInfo;
+int sol_scene_info(const SolScene* scene, SolSceneInfo* out);
 
 /* Scheduler options of a live handle (take effect at the next sol_render; results never depend on them). */
 #define SOL_OPT_SWITCH_BELOW 1        /* 0..64: a wave leaves the search loop when fewer 64ths of its lanes search      */

@@ -7,6 +7,8 @@ hipcc cross-compiles gfx950 code objects without a GPU. -ffp-contract=off keeps 
 IEEE sequence the parity tests pin (DESIGN.md "fp32 arithmetic contract"). Translation units are compiled in
 parallel to objects (only the stale ones) and linked; `build(out_dir=..., extra_hip_flags=...)` makes an A/B variant
 of the device library elsewhere (tests/tools/variants.py), selected at run time through SOLSTRALE_BUILD_DIR.
+`build_ab()` makes _build_ab/: the same library plus the two wavefront render-kernel variants (-DSOL_AB_KERNELS), which the
+product library does not carry.
 """
 import os
 import subprocess
@@ -17,9 +19,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 BUILD = os.path.join(HERE, "_build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SRC = ["csrc/sol_render.hip", "csrc/sol_wavefront.hip", "csrc/sol_aux.hip", "csrc/sol_build.hip", "csrc/sol_api.cpp"]
+HIP_SRC = ["csrc/sol_render.hip", "csrc/sol_aux.hip", "csrc/sol_build.hip", "csrc/sol_api.cpp", "csrc/sol_create.cpp",
+           "csrc/sol_launch.cpp", "csrc/sol_post.cpp", "csrc/sol_comm.cpp"]
 HIP_HDR = ["csrc/sol_types.h", "csrc/sol_math.h", "csrc/sol_trace.h", "csrc/sol_shade.h", "csrc/sol_path.h", "csrc/sol_launch.h",
-           "csrc/sol_tree.h", "csrc/sol_build.h", "../include/solstrale_hip.h"]
+           "csrc/sol_tree.h", "csrc/sol_build.h", "csrc/sol_scene.h", "../include/solstrale_hip.h"]
 HOST_SRC = ["host/solstrale_host.cpp", "host/solstrale_obj.cpp", "host/solstrale_host_c.cpp"]
 HOST_DEPS = HOST_SRC + ["host/solstrale.hpp", "../include/solstrale_hip.h", "../include/solstrale_host.h"]
 
@@ -39,17 +42,22 @@ def _run(cmd):
     subprocess.check_call(cmd, cwd=HERE)
 
 
-def build(force=False, extra_hip_flags=(), out_dir=None):
+def build(force=False, extra_hip_flags=(), out_dir=None, ab_kernels=False):
+    """Product library into _build/ (or a variant into out_dir). ab_kernels: the A/B build that also carries the two wavefront
+    render kernels (-DSOL_AB_KERNELS + sol_wavefront.hip; `build_ab()` puts it into _build_ab/) - the product has one family."""
     out_dir = out_dir or BUILD
     os.makedirs(out_dir, exist_ok=True)
     hip_lib = os.path.join(out_dir, "libsolstrale_hip.so")
     host_lib = os.path.join(out_dir, "libsolstrale_host.so")
     flags_file = os.path.join(out_dir, "hip_flags.txt")
-    flags = HIP_FLAGS + list(extra_hip_flags)
-    if not os.path.exists(flags_file) or open(flags_file).read() != " ".join(flags):
+    flags = HIP_FLAGS + (["-DSOL_AB_KERNELS"] if ab_kernels else []) + list(extra_hip_flags)
+    sources = HIP_SRC + (["csrc/sol_wavefront.hip"] if ab_kernels else [])
+    if not os.path.exists(flags_file) or open(flags_file).read() != " ".join(flags + sources):
         force = True
+        if os.path.exists(flags_file):
+            os.remove(flags_file)  # (written again only after a successful link: an interrupted build starts over)
     jobs, objs = [], []
-    for src in HIP_SRC:
+    for src in sources:
         obj = os.path.join(out_dir, os.path.basename(src) + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + HIP_HDR + ["build.py"]):
@@ -57,14 +65,24 @@ def build(force=False, extra_hip_flags=(), out_dir=None):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             list(ex.map(_run, jobs))
-        open(flags_file, "w").write(" ".join(flags))
-    if jobs or not os.path.exists(hip_lib):
+    # link whenever an object is newer than the library (also after a failed or interrupted link of an earlier run)
+    if jobs or not os.path.exists(hip_lib) or any(os.path.getmtime(o) > os.path.getmtime(hip_lib) for o in objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", hip_lib, "-ldl"])
+    open(flags_file, "w").write(" ".join(flags + sources))
     if force or _stale(host_lib, HOST_DEPS + ["build.py"]) or os.path.getmtime(hip_lib) > os.path.getmtime(host_lib):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-pthread"] + HOST_SRC +
              ["-o", host_lib, "-L" + out_dir, "-lsolstrale_hip", "-Wl,-rpath,$ORIGIN"])
     return hip_lib, host_lib
 
 
+BUILD_AB = os.path.join(HERE, "_build_ab")
+
+
+def build_ab(force=False):
+    return build(force=force, out_dir=BUILD_AB, ab_kernels=True)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--ab" in sys.argv:
+        build_ab(force="--force" in sys.argv)

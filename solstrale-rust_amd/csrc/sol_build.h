@@ -27,6 +27,7 @@ struct SolDeviceTree {
 
 // Builds the 7-wide tree over `prims` (host memory, n >= 1, every reference at most once) on the current HIP device.
 // root_box: box of all primitives; pad: the scene's fp32 box pad; emin: smallest biased exponent of a node scale
-// (WideBuilder::exponent_min); counts: sizes of the triangle / sphere / quad arrays. False + message on failure.
+// (WideBuilder::exponent_min); counts: sizes of the triangle / sphere / quad arrays; ploc_radius: neighbours searched to each side in a
+// clustering round (0: the default, 16). False + message on failure.
 bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const float root_box[6], float pad, uint32_t emin, const uint32_t counts[3],
-                                 hipStream_t stream, SolDeviceTree& out, std::string& err);
+                                 int ploc_radius, hipStream_t stream, SolDeviceTree& out, std::string& err);

@@ -420,8 +420,15 @@ struct Scratch {  // device allocations of one build, freed on every path
     if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } \
   } while (0)
 
+// a launch that fails (bad configuration, no code object for the device) is reported under the kernel's own name
+#define B_LAUNCHED(kernel)                                                                                   \
+  do {                                                                                                        \
+    hipError_t e_ = hipGetLastError();                                                                        \
+    if (e_ != hipSuccess) { err = std::string("launch of " #kernel ": ") + hipGetErrorString(e_); return false; } \
+  } while (0)
+
 bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const float root_box[6], float pad, uint32_t emin, const uint32_t counts[3],
-                                 hipStream_t stream, SolDeviceTree& out, std::string& err) {
+                                 int ploc_radius, hipStream_t stream, SolDeviceTree& out, std::string& err) {
   if (n == 0 || n > (SOL_WIDE_MAX_INDEX >> 1)) { err = "device tree build: primitive count out of range"; return false; }
   Scratch S;
   const uint32_t n_nodes = 2 * n - 1;
@@ -448,6 +455,7 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const fl
     inv[a] = (ext[a] > 0.f && ext[a] < 1e30f) ? 2097152.0f / ext[a] : 0.f;
   }
   hipLaunchKernelGGL(k_morton, dim3(nb), dim3(BT), 0, stream, d_prims, n, root_box[0], root_box[2], root_box[4], inv[0], inv[1], inv[2], keys, vals);
+  B_LAUNCHED(k_morton);
   size_t tmp_bytes = 0, scan_bytes = 0;
   B_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, order, (size_t)n, 0, 63, stream));
   B_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, offset, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
@@ -455,6 +463,7 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const fl
   B_TRY(S.get(&tmp, tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes));
   B_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, order, (size_t)n, 0, 63, stream));
   hipLaunchKernelGGL(k_leaves, dim3(nb), dim3(BT), 0, stream, d_prims, order, n, nbox, cl_a, parent);
+  B_LAUNCHED(k_leaves);
   // ---- 2. PLOC ----
   const uint32_t init_counters[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, n /* next free binary node */};
   B_TRY(hipMemcpyAsync(counters, init_counters, sizeof init_counters, hipMemcpyHostToDevice, stream));
@@ -462,15 +471,18 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const fl
   // 12: 10.91 / 12.94 / 7.67, 16: 10.85 / 12.98 / 6.93, 24: 10.30 / 13.06 / 7.77, 32: 9.90 / 13.08 / 7.40, 64: 10.97 / 13.73 / 7.24 - not
   // monotonic (greedy clustering); 16 is within 3 % of the host trees on the triangle scenes
   int radius = 16;
-  if (const char* e = std::getenv("SOL_PLOC_R")) radius = std::max(1, std::min(PLOC_R_MAX, std::atoi(e)));  // (experiment knob)
+  if (ploc_radius > 0) radius = std::min(PLOC_R_MAX, ploc_radius);  // (experiment knob: SOL_PLOC_R)
   uint32_t cur_n = n, rounds = 0;
   uint32_t *cin = cl_a, *cout = cl_b;
   while (cur_n > 1) {
     const uint32_t g = (cur_n + BT - 1) / BT;
     hipLaunchKernelGGL(k_nn, dim3(g), dim3(BT), 0, stream, cin, cur_n, nbox, radius, nn);
+    B_LAUNCHED(k_nn);
     hipLaunchKernelGGL(k_merge, dim3(g), dim3(BT), 0, stream, cin, cur_n, nn, nbox, left, right, parent, counters + 7, out_node, flag);
+    B_LAUNCHED(k_merge);
     B_TRY(rocprim::exclusive_scan(tmp, scan_bytes, flag, offset, 0u, (size_t)cur_n, rocprim::plus<uint32_t>(), stream));
     hipLaunchKernelGGL(k_compact, dim3(g), dim3(BT), 0, stream, out_node, flag, offset, cur_n, cout);
+    B_LAUNCHED(k_compact);
     uint32_t last[2];
     B_TRY(hipMemcpyAsync(&last[0], offset + (cur_n - 1), 4, hipMemcpyDeviceToHost, stream));
     B_TRY(hipMemcpyAsync(&last[1], flag + (cur_n - 1), 4, hipMemcpyDeviceToHost, stream));
@@ -484,6 +496,7 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const fl
   B_TRY(hipMemcpyAsync(&root_node, cin, 4, hipMemcpyDeviceToHost, stream));
   // ---- 3. collapse costs ----
   hipLaunchKernelGGL(k_collapse_cost, dim3(nb), dim3(BT), 0, stream, n, parent, left, right, nbox, arrived, dp);
+  B_LAUNCHED(k_collapse_cost);
   B_TRY(hipStreamSynchronize(stream));
   // ---- 4. emission, level by level ----
   EmitParams P;
@@ -498,12 +511,16 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const fl
     if (++depth > 256) { err = "device tree build: tree deeper than 256 wide levels"; return false; }
     B_TRY(hipMemsetAsync(counters + 1, 0, 4, stream));
     hipLaunchKernelGGL(k_emit, dim3((n_front + 63) / 64), dim3(64), 0, stream, P, fin, n_front, fout);
+    B_LAUNCHED(k_emit);
     B_TRY(hipMemcpyAsync(&n_front, counters + 1, 4, hipMemcpyDeviceToHost, stream));
     B_TRY(hipStreamSynchronize(stream));
     Frontier* t = fin; fin = fout; fout = t;
   }
   for (int a = 0; a < 3; ++a)
-    if (counts[a]) hipLaunchKernelGGL(k_rest, dim3((counts[a] + BT - 1) / BT), dim3(BT), 0, stream, new_index[a], counts[a], counters + 3 + a);
+    if (counts[a]) {
+      hipLaunchKernelGGL(k_rest, dim3((counts[a] + BT - 1) / BT), dim3(BT), 0, stream, new_index[a], counts[a], counters + 3 + a);
+      B_LAUNCHED(k_rest);
+    }
   uint32_t fin_counters[8];
   B_TRY(hipMemcpyAsync(fin_counters, counters, sizeof fin_counters, hipMemcpyDeviceToHost, stream));
   B_TRY(hipStreamSynchronize(stream));

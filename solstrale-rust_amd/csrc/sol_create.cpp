@@ -1,0 +1,659 @@
+// sol_create.cpp -- sol_scene_create: validation of the flattened scene, conversion to the fp32 device layout (sol_types.h),
+// the world tree (built on the GPU by sol_build.hip, or host candidates + probe), upload, work-order probe; sol_world_tree_check.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <future>
+#include <limits>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "sol_build.h"
+#include "sol_scene.h"
+#include "sol_tree.h"
+
+// The world tree built on the GPU (sol_build.hip): primitives of the reference-shaped tree under `root_ref` (each once - a
+// shared sub-tree is the same geometry twice, one copy finds the same hits), clustered and collapsed on the current device.
+static int device_world_tree(const std::vector<DNode>& bin, uint32_t root_ref, const Box& root_box, float box_pad, const uint32_t counts[3],
+                             int ploc_radius, hipStream_t stream, WideLayout& lay, uint32_t& emin) {
+  std::vector<SolBuildPrim> prims;
+  if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) {
+    SahBuilder col;
+    if (!col.collect(bin, root_ref)) return sol_fail(SOL_EINVAL, "the world's primitives cannot be collected (non-finite box or fewer than two)");
+    std::sort(col.prims.begin(), col.prims.end(), [](const SahBuilder::Prim& a, const SahBuilder::Prim& b) { return a.ref < b.ref; });
+    prims.reserve(col.prims.size());
+    for (size_t i = 0; i < col.prims.size(); ++i) {
+      if (i && col.prims[i].ref == col.prims[i - 1].ref) continue;
+      SolBuildPrim p;
+      for (int k = 0; k < 6; ++k) p.box[k] = col.prims[i].box.v[k];
+      p.ref = col.prims[i].ref; p.pad = 0;
+      prims.push_back(p);
+    }
+  } else {
+    SolBuildPrim p;
+    for (int k = 0; k < 6; ++k) p.box[k] = root_box.v[k];
+    p.ref = root_ref; p.pad = 0;
+    prims.push_back(p);
+  }
+  emin = WideBuilder::exponent_min(root_box, box_pad);
+  SolDeviceTree dt;
+  std::string err;
+  if (!sol_build_world_tree_device(prims.data(), (uint32_t)prims.size(), root_box.v, box_pad, emin, counts, ploc_radius, stream, dt, err)) return sol_fail(SOL_EDEVICE, "%s", err.c_str());
+  if (!lay.adopt_device(std::move(dt.nodes), std::move(dt.leaf_refs), dt.new_of_old, dt.depth)) return sol_fail(SOL_EDEVICE, "%s", lay.error.c_str());
+  return SOL_OK;
+}
+
+extern "C" {
+
+int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) {
+  if (!d || !out) return sol_fail(SOL_EINVAL, "null argument");
+  std::memset(out, 0, sizeof *out);
+  const SolDevOverrides ovr = sol_dev_overrides();
+  const float box_pad = box_pad_for(*d);
+  TreeBuilder tb(*d, box_pad);
+  uint32_t root_ref;
+  Box root_box;
+  if (!tb.resolve(d->root, 0, root_ref, root_box)) return sol_fail(SOL_EINVAL, "world: %s", tb.error.c_str());
+  if (SOL_REF_KIND(root_ref) != SOL_REF_NODE) return sol_fail(SOL_EINVAL, "the world is a single primitive: no tree");
+  SahBuilder sah;
+  if (!sah.collect(tb.nodes, root_ref)) return sol_fail(SOL_EINVAL, "the world's primitives cannot be collected (non-finite box or fewer than two)");
+  std::map<uint32_t, int> expected;  // primitive reference -> multiplicity
+  std::map<uint32_t, Box> prim_box;
+  for (const auto& p : sah.prims) { expected[p.ref]++; prim_box[p.ref] = p.box; }
+  if (use_sah < 0)
+    for (auto& e : expected) e.second = 1;  // (the device build keeps one copy of a shared sub-tree's primitives)
+  out->n_primitives = (uint32_t)sah.prims.size();
+  if (use_sah < 0) out->n_primitives = (uint32_t)expected.size();
+  WideLayout lay;
+  uint32_t emin_used = 1;
+  double inner_area = 0., leaf_area = 0.;
+  if (use_sah < 0) {  // the tree sol_build.hip builds on the GPU, checked like the host-built ones
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sol_fail(SOL_EDEVICE, "no HIP device available");
+    HIP_TRY(hipSetDevice(0));
+    const uint32_t counts[3] = {d->n_triangles, d->n_spheres, d->n_quads};
+    int rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, ovr.ploc_radius, nullptr, lay, emin_used);
+    if (rc) return rc;
+  } else {
+    uint32_t bin_root = root_ref;
+    if (use_sah) { Box b; sah.BINS = use_sah > 1 ? std::min((int)SahBuilder::MAX_BINS, use_sah) : 16; bin_root = sah.build(0, sah.prims.size(), 0, b); }
+    WideBuilder wb(use_sah ? sah.nodes : tb.nodes, box_pad);
+    wb.dp_collapse = !ovr.greedy_collapse;
+    wb.slot_by_assignment = !ovr.octant_slots;
+    wb.NODE_COST = ovr.node_cost;
+    wb.set_exponent_range(root_box);
+    const uint32_t xroot = wb.build(SOL_REF_INDEX(bin_root), 0);
+    if (wb.range_error || !lay.run(wb.out, SOL_REF_INDEX(xroot), wb.emin, d->n_triangles, d->n_spheres, d->n_quads))
+      return sol_fail(SOL_EINVAL, "wide tree layout: %s", wb.range_error ? "exponent range" : lay.error.c_str());
+    emin_used = wb.emin;
+    inner_area = wb.inner_area; leaf_area = wb.leaf_area;
+  }
+  out->n_wide = (uint32_t)lay.nodes.size();
+  out->depth = lay.depth;
+  out->inner_area = inner_area; out->leaf_area = leaf_area;
+  std::map<uint32_t, int> found;
+  // The DEVICE form is what gets checked, decoded exactly as the kernel decodes it (sol_trace.h): 5-bit exponents over emin,
+  // implicit child addresses, permuted primitive arrays (mapped back to the caller's indices for the comparison).
+  const uint32_t ref_kind_of[4] = {SOL_REF_NONE, SOL_REF_TRIANGLE, SOL_REF_SPHERE, SOL_REF_QUAD};
+  // returns the union of the padded primitive boxes below node `ni`
+  std::function<Box(uint32_t, uint32_t)> walk = [&](uint32_t ni, uint32_t depth) -> Box {
+    Box all = empty_box();
+    if (depth > 4096 || ni >= lay.nodes.size()) { out->leaf_mismatches++; return all; }
+    const DWide& w = lay.nodes[ni];
+    const float origin[3] = {w.ox, w.oy, w.oz};
+    float scale[3];
+    for (int a = 0; a < 3; ++a) { uint32_t bits = (((w.meta >> (5 * a)) & 31u) + emin_used) << 23; std::memcpy(&scale[a], &bits, 4); }
+    const uint32_t imask = (w.meta >> 15) & 0x7Fu, lmask = (w.meta >> 22) & 0x7Fu, kind = (w.meta >> 29) & 3u;
+    if (imask & lmask) out->bad_empty_slots++;
+    uint32_t n_children = 0;
+    for (int s = 0; s < SOL_WIDE_CHILDREN; ++s) {
+      uint32_t ql[3], qh[3];
+      for (int a = 0; a < 3; ++a) {
+        ql[a] = (w.q[2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xFFu;
+        qh[a] = (w.q[6 + 2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xFFu;
+      }
+      const uint32_t bit = 1u << s, below_mask = bit - 1u;
+      if (!((imask | lmask) & bit)) {  // an empty slot must have an inverted box (never hit)
+        if (!(ql[0] == 255u && qh[0] == 0u && ql[1] == 255u && qh[1] == 0u && ql[2] == 255u && qh[2] == 0u)) out->bad_empty_slots++;
+        continue;
+      }
+      n_children++;
+      Box below;
+      if (imask & bit) {
+        below = walk(WideLayout::base_inner(w) + (uint32_t)__builtin_popcount(imask & below_mask), depth + 1);
+      } else {
+        const uint32_t idx = WideLayout::base_prim(w) + (uint32_t)__builtin_popcount(lmask & below_mask);
+        uint32_t ref = kind == SOL_LEAF_REFS ? (idx < lay.leaf_refs.size() ? lay.leaf_refs[idx] : 0u) : SOL_MAKE_REF(ref_kind_of[kind], idx);
+        const int a = WideLayout::arr(SOL_REF_KIND(ref));
+        if (a >= 0) ref = SOL_REF_INDEX(ref) < lay.old_of_new[a].size() ? SOL_MAKE_REF(SOL_REF_KIND(ref), lay.old_of_new[a][SOL_REF_INDEX(ref)]) : 0u;
+        found[ref]++;
+        out->n_leaf_refs++;
+        auto it = prim_box.find(ref);
+        below = it == prim_box.end() ? empty_box() : it->second;
+      }
+      bool ok = true;
+      for (int a = 0; a < 3; ++a) {
+        const float lo = WideBuilder::decode(origin[a], ql[a], scale[a]), hi = WideBuilder::decode(origin[a], qh[a], scale[a]);
+        if (below.v[2 * a] <= below.v[2 * a + 1] && !(lo <= below.v[2 * a] && hi >= below.v[2 * a + 1])) ok = false;
+      }
+      if (!ok) out->box_violations++;
+      SahBuilder::grow(all, below);
+    }
+    if (n_children > out->max_children) out->max_children = n_children;
+    return all;
+  };
+  walk(0, 0);
+  // the permutations must be permutations
+  for (int a = 0; a < 3; ++a) {
+    std::vector<uint8_t> seen(lay.old_of_new[a].size(), 0);
+    for (uint32_t o : lay.old_of_new[a]) { if (o >= seen.size() || seen[o]) out->leaf_mismatches++; else seen[o] = 1; }
+    if (lay.old_of_new[a].size() != lay.new_of_old[a].size()) out->leaf_mismatches++;
+  }
+  for (const auto& e : expected) {
+    auto it = found.find(e.first);
+    const int f = it == found.end() ? 0 : it->second;
+    if (f != e.second) out->leaf_mismatches += (uint32_t)std::abs(f - e.second);
+  }
+  for (const auto& f : found)
+    if (!expected.count(f.first)) out->leaf_mismatches += (uint32_t)f.second;
+  return SOL_OK;
+}
+
+int sol_scene_create(const SolSceneDesc* d, int device, SolScene** out) { return sol_scene_create_ex(d, device, nullptr, out); }
+
+int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOptions* opt_in, SolScene** out) {
+  if (!d || !out) return sol_fail(SOL_EINVAL, "null argument");
+  *out = nullptr;
+  const SolDevOverrides ovr = sol_dev_overrides();
+  SolCreateOptions opt{};
+  if (opt_in) {
+    if (opt_in->size < 8 || opt_in->size > 4096) return sol_fail(SOL_EINVAL, "SolCreateOptions.size %u", opt_in->size);
+    std::memcpy(&opt, opt_in, std::min<size_t>(opt_in->size, sizeof opt));
+  }
+  if (opt.world_tree < SOL_TREE_AUTO || opt.world_tree > SOL_TREE_HOST_PROBE) return sol_fail(SOL_EINVAL, "bad world_tree option %d", opt.world_tree);
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto seconds_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  if (d->abi_version != SOL_ABI_VERSION && d->abi_version != 1u) return sol_fail(SOL_EINVAL, "abi_version %u, expected %u (or 1)", d->abi_version, SOL_ABI_VERSION);
+  const bool has_env = d->abi_version >= 2u && d->env_texels && d->env_width && d->env_height;  // (a version-1 description ends before these fields)
+  if (has_env && ((uint64_t)d->env_width * d->env_height > (1ull << 28) || !std::isfinite(d->env_scale))) return sol_fail(SOL_EINVAL, "bad environment map");
+  if (d->width < 2 || d->height < 2 || (uint64_t)d->width * d->height > 0x3FFFFFFFull) return sol_fail(SOL_EINVAL, "bad image size %ux%u", d->width, d->height);
+  if (d->shader_kind > SOL_SHADER_SIMPLE) return sol_fail(SOL_EINVAL, "bad shader kind %u", d->shader_kind);
+  if ((d->n_nodes && !d->nodes) || (d->n_spheres && !d->spheres) || (d->n_quads && !d->quads) ||
+      (d->n_triangles && !d->triangles) || (d->n_mediums && !d->mediums) || (d->n_materials && !d->materials) ||
+      (d->n_textures && !d->textures) || (d->n_texel_bytes && !d->texels) || (d->n_lights && !d->lights))
+    return sol_fail(SOL_EINVAL, "null array with non-zero count");
+  // Renderer::new: "Scene should have at least one light" (src/renderer/mod.rs:143-147)
+  if (d->n_lights == 0) return sol_fail(SOL_ENOLIGHT, "Scene should have at least one light");
+  if (d->n_texel_bytes > 0xFFFFFFF0ull) return sol_fail(SOL_EINVAL, "more than 4 GiB of texels");
+
+  // ---- materials / textures ----
+  std::vector<DTex> texs(d->n_textures);
+  for (uint32_t i = 0; i < d->n_textures; ++i) {
+    const SolTexture& t = d->textures[i];
+    DTex& o = texs[i];
+    std::memset(&o, 0, sizeof o);
+    o.kind = t.kind;
+    if (t.kind == SOL_TEX_IMAGE) {
+      if (!t.width || !t.height || t.texel_offset + (uint64_t)t.width * t.height * 3 > d->n_texel_bytes)
+        return sol_fail(SOL_EINVAL, "texture %u: image outside texel buffer", i);
+      o.w = t.width; o.h = t.height; o.offset = (uint32_t)t.texel_offset;
+    } else if (t.kind == SOL_TEX_SOLID) {
+      o.r = (float)t.rgb[0]; o.g = (float)t.rgb[1]; o.b = (float)t.rgb[2];
+    } else {
+      return sol_fail(SOL_EINVAL, "texture %u: bad kind %d", i, t.kind);
+    }
+  }
+  auto tex_ok = [&](int32_t id, bool optional) { return (optional && id < 0) || (id >= 0 && (uint32_t)id < d->n_textures); };
+  std::vector<DMat> mats(d->n_materials);
+  for (uint32_t i = 0; i < d->n_materials; ++i) {
+    const SolMaterial& m = d->materials[i];
+    DMat& o = mats[i];
+    std::memset(&o, 0, sizeof o);
+    o.kind = m.kind; o.albedo = m.albedo_tex; o.normal = m.normal_tex; o.m1 = m.m1; o.m2 = m.m2;
+    o.param = (float)m.param;
+    if (std::isnan(m.param)) o.flags |= DMAT_PARAM_NONE;
+    if (m.kind != SOL_MAT_BLEND && m.albedo_tex >= 0 && (uint32_t)m.albedo_tex < d->n_textures && texs[m.albedo_tex].kind == SOL_TEX_SOLID) {
+      o.flags |= DMAT_ALBEDO_SOLID;
+      o.ar = texs[m.albedo_tex].r; o.ag = texs[m.albedo_tex].g; o.ab = texs[m.albedo_tex].b;
+    }
+    switch (m.kind) {
+      case SOL_MAT_LAMBERTIAN: case SOL_MAT_METAL: case SOL_MAT_DIELECTRIC:
+        if (!tex_ok(m.albedo_tex, false) || !tex_ok(m.normal_tex, true)) return sol_fail(SOL_EINVAL, "material %u: bad texture id", i);
+        break;
+      case SOL_MAT_DIFFUSE_LIGHT: case SOL_MAT_ISOTROPIC:
+        if (!tex_ok(m.albedo_tex, false)) return sol_fail(SOL_EINVAL, "material %u: bad texture id", i);
+        o.normal = -1;
+        break;
+      case SOL_MAT_BLEND:
+        if (m.m1 < 0 || m.m2 < 0 || (uint32_t)m.m1 >= d->n_materials || (uint32_t)m.m2 >= d->n_materials || (uint32_t)m.m1 == i || (uint32_t)m.m2 == i)
+          return sol_fail(SOL_EINVAL, "material %u: bad blend children", i);
+        break;
+      default: return sol_fail(SOL_EINVAL, "material %u: bad kind %d", i, m.kind);
+    }
+  }
+  // NEEDS_UV: any image texture reachable from the material (Blend children included; bounded iteration)
+  for (int pass = 0; pass < 16; ++pass)
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+      DMat& o = mats[i];
+      bool need = false;
+      if (o.kind == SOL_MAT_BLEND) need = (mats[o.m1].flags | mats[o.m2].flags) & DMAT_NEEDS_UV;
+      else need = (o.albedo >= 0 && texs[o.albedo].kind == SOL_TEX_IMAGE) || (o.normal >= 0 && texs[o.normal].kind == SOL_TEX_IMAGE);
+      if (need) o.flags |= DMAT_NEEDS_UV;
+    }
+  auto mat_ok = [&](int32_t id) { return id >= 0 && (uint32_t)id < d->n_materials; };
+
+  // ---- primitives (plain casts) ----
+  std::vector<DTri> tris(d->n_triangles);
+  std::vector<DTriShade> tshade(d->n_triangles);
+  for (uint32_t i = 0; i < d->n_triangles; ++i) {
+    const SolTriangle& t = d->triangles[i];
+    if (!mat_ok(t.material)) return sol_fail(SOL_EINVAL, "triangle %u: bad material", i);
+    DTri& o = tris[i];
+    o.v0x = (float)t.v0[0]; o.v0y = (float)t.v0[1]; o.v0z = (float)t.v0[2];
+    o.e1x = (float)t.v0v1[0]; o.e1y = (float)t.v0v1[1]; o.e1z = (float)t.v0v1[2];
+    o.e2x = (float)t.v0v2[0]; o.e2y = (float)t.v0v2[1]; o.e2z = (float)t.v0v2[2];
+    o.dfs = t.dfs_index; o.mat = t.material; o.area = (float)t.area;
+    DTriShade& s = tshade[i];
+    s.nx = (float)t.normal[0]; s.ny = (float)t.normal[1]; s.nz = (float)t.normal[2]; s.mat = t.material;
+    s.tx = (float)t.tangent[0]; s.ty = (float)t.tangent[1]; s.tz = (float)t.tangent[2];
+    s.bx = (float)t.bi_tangent[0]; s.by = (float)t.bi_tangent[1]; s.bz = (float)t.bi_tangent[2];
+    s.u0 = t.uv0[0]; s.v0 = t.uv0[1]; s.u1 = t.uv1[0]; s.v1 = t.uv1[1]; s.u2 = t.uv2[0]; s.v2 = t.uv2[1];
+  }
+  std::vector<DQuad> quads(d->n_quads);
+  for (uint32_t i = 0; i < d->n_quads; ++i) {
+    const SolQuad& q = d->quads[i];
+    if (!mat_ok(q.material)) return sol_fail(SOL_EINVAL, "quad %u: bad material", i);
+    DQuad& o = quads[i];
+    o.nx = (float)q.normal[0]; o.ny = (float)q.normal[1]; o.nz = (float)q.normal[2]; o.d = (float)q.d;
+    o.qx = (float)q.q[0]; o.qy = (float)q.q[1]; o.qz = (float)q.q[2]; o.dfs = q.dfs_index;
+    o.wx = (float)q.w[0]; o.wy = (float)q.w[1]; o.wz = (float)q.w[2]; o.mat = q.material;
+    o.ux = (float)q.u[0]; o.uy = (float)q.u[1]; o.uz = (float)q.u[2]; o.area = (float)q.area;
+    o.vx = (float)q.v[0]; o.vy = (float)q.v[1]; o.vz = (float)q.v[2]; o.pad = 0.f;
+  }
+  std::vector<DSphere> spheres(d->n_spheres);
+  for (uint32_t i = 0; i < d->n_spheres; ++i) {
+    const SolSphere& s = d->spheres[i];
+    if (!mat_ok(s.material)) return sol_fail(SOL_EINVAL, "sphere %u: bad material", i);
+    DSphere& o = spheres[i];
+    o.cx = (float)s.center[0]; o.cy = (float)s.center[1]; o.cz = (float)s.center[2]; o.radius = (float)s.radius;
+    o.dfs = s.dfs_index; o.mat = s.material; o.pad0 = o.pad1 = 0;
+  }
+
+  // ---- tree ----
+  const float box_pad = box_pad_for(*d);
+  TreeBuilder tb(*d, box_pad);
+  uint32_t root_ref;
+  Box root_box;
+  if (!tb.resolve(d->root, 0, root_ref, root_box)) return sol_fail(SOL_EINVAL, "world: %s", tb.error.c_str());
+  if (SOL_REF_KIND(root_ref) == SOL_REF_NONE) return sol_fail(SOL_EINVAL, "world is empty");
+  const uint32_t world_depth = tb.max_depth;
+  std::vector<DMedium> mediums(d->n_mediums);
+  uint32_t medium_depth = 0;
+  for (uint32_t i = 0; i < d->n_mediums; ++i) {
+    const SolMedium& m = d->mediums[i];
+    if (!mat_ok(m.material)) return sol_fail(SOL_EINVAL, "medium %u: bad material", i);
+    if (i >= 0x1000u) return sol_fail(SOL_EINVAL, "more than 4096 constant mediums");
+    DMedium& o = mediums[i];
+    std::memset(&o, 0, sizeof o);
+    tb.max_depth = 0;
+    uint32_t bref;
+    Box bb;
+    if (!tb.resolve(m.boundary, 0, bref, bb)) return sol_fail(SOL_EINVAL, "medium %u boundary: %s", i, tb.error.c_str());
+    if (SOL_REF_KIND(bref) == SOL_REF_MEDIUM || SOL_REF_KIND(bref) == SOL_REF_NONE) return sol_fail(SOL_EINVAL, "medium %u: unsupported boundary", i);
+    medium_depth = std::max(medium_depth, tb.max_depth);
+    o.boundary = bref; o.mat = m.material; o.nid = (float)m.negative_inverse_density; o.dfs = m.dfs_index;
+    o.bxmin = bb.v[0]; o.bxmax = bb.v[1]; o.bymin = bb.v[2]; o.bymax = bb.v[3]; o.bzmin = bb.v[4]; o.bzmax = bb.v[5];
+  }
+  // a medium inside a medium boundary would recurse in the device search: reject (never built by the reference's scenes)
+  for (uint32_t i = 0; i < d->n_mediums; ++i) {
+    std::vector<uint32_t> stk{mediums[i].boundary};
+    while (!stk.empty()) {
+      uint32_t r = stk.back(); stk.pop_back();
+      if (SOL_REF_KIND(r) == SOL_REF_MEDIUM) return sol_fail(SOL_EINVAL, "medium %u: nested ConstantMedium in a boundary is unsupported", i);
+      if (SOL_REF_KIND(r) == SOL_REF_NODE) { stk.push_back(tb.nodes[SOL_REF_INDEX(r)].left); stk.push_back(tb.nodes[SOL_REF_INDEX(r)].right); }
+    }
+  }
+  // 7-wide tree of the world. Candidates: the reference's topology collapsed, and binned-SAH rebuilds over the same primitives
+  // with 8, 16 and 64 bins (how well the binary splits line up with the wide collapse varies with the bin count: with the
+  // first, 8-wide layout C2 visited 9.8 / 12.2 / 11.4 nodes per ray at 8 / 16 / 64 bins and 11.2 on the reference's
+  // topology; C3 13.3 / 13.0 / 12.9 vs 14.4). A counted probe render on the device picks one (below).
+  // SolCreateOptions.world_tree (or SOL_BVH=ref | sah (16 bins) | sah8 | sah16 | sah64) forces a candidate.
+  struct TreeCand {
+    std::string name;
+    std::unique_ptr<SahBuilder> sah;
+    std::unique_ptr<WideBuilder> wb;
+    WideLayout lay;
+    uint32_t depth = 0, emin = 1;
+    DevTree dev;
+    double cost = 0.;
+  };
+  std::vector<TreeCand> cands;
+  // stack entries (dwords): a wide level keeps at most one sibling group of two dwords
+  auto depth_of = [&](const WideLayout& l) { return (SOL_WORLD_BINARY ? world_depth : 2u * l.depth) + medium_depth + 2; };
+  const uint32_t stack_limit = SOL_LDS_STACK + SOL_SPILL_STACK;
+  // AUTO = the device build: as good a tree as the probed host candidates (node visits per ray, host probe / device: C2 11.0 /
+  // 10.9, C3 12.8 / 13.0, C5 6.8 / 6.9) in a sixth to an eighth of the time (sol_scene_create, C3: 0.40 s -> 0.06 s, C5 2.2 s -> 0.3 s)
+  static const char* const tree_names[] = {"device", "ref", "sah8", "sah16", "sah64", "device", ""};
+  std::string want = !ovr.bvh.empty() ? ovr.bvh : tree_names[opt.world_tree];  // (SOL_BVH: developer override of SolCreateOptions.world_tree)
+  if (want == "host") want = "";  // all host candidates + the probe
+  auto tune = [&](WideBuilder& wb) { wb.dp_collapse = !ovr.greedy_collapse; wb.slot_by_assignment = !ovr.octant_slots; wb.NODE_COST = ovr.node_cost; };
+  auto finish_cand = [&](TreeCand& c, uint32_t wide_root) {  // explicit tree -> device layout
+    if (c.wb->range_error || !c.lay.run(c.wb->out, SOL_REF_INDEX(wide_root), c.wb->emin, d->n_triangles, d->n_spheres, d->n_quads)) {
+      c.wb.reset();
+      return;
+    }
+    c.depth = depth_of(c.lay);
+    c.emin = c.wb->emin;
+  };
+  // The host candidates wanted by `want` ("" = all of them, the probe decides): into `cands`, the provisional best first.
+  auto host_candidates = [&](const std::string& want) -> int {
+  std::string layout_error;
+  if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) {
+    {
+      TreeCand c;
+      c.name = "ref";
+      c.wb.reset(new WideBuilder(tb.nodes, box_pad));
+      tune(*c.wb);
+      c.wb->set_exponent_range(root_box);
+      finish_cand(c, c.wb->build(SOL_REF_INDEX(root_ref), 0));
+      if (!c.wb) layout_error = c.lay.error.empty() ? "wide tree: exponent range" : c.lay.error;
+      else cands.push_back(std::move(c));
+    }
+    std::vector<int> bin_list = {8, 16, 64};
+    if (!ovr.sah_bins.empty()) bin_list = ovr.sah_bins;  // (SOL_SAH_LIST)
+    // (the rebuilds are independent of each other: one host thread each)
+    std::vector<std::future<TreeCand>> jobs;
+    for (int bins : bin_list) {
+      const std::string name = "sah" + std::to_string(bins);
+      if (want == "ref" || (!want.empty() && want != name)) continue;
+      jobs.push_back(std::async(std::launch::async, [&, bins, name]() {
+        TreeCand c;
+        c.name = name;
+        c.sah.reset(new SahBuilder());
+        c.sah->BINS = bins;
+        if (!c.sah->collect(tb.nodes, root_ref)) return c;  // non-finite boxes or a single primitive: no rebuild (wb stays null)
+        Box bx;
+        const uint32_t r = c.sah->build(0, c.sah->prims.size(), 0, bx);
+        c.wb.reset(new WideBuilder(c.sah->nodes, box_pad));
+        tune(*c.wb);
+        c.wb->set_exponent_range(root_box);
+        finish_cand(c, c.wb->build(SOL_REF_INDEX(r), 0));
+        return c;
+      }));
+    }
+    for (auto& j : jobs) {
+      TreeCand c = j.get();
+      if (c.wb) cands.push_back(std::move(c));
+    }
+    if (cands.empty()) return sol_fail(SOL_EINVAL, "world: %s", layout_error.c_str());
+    // drop what cannot run; a forced choice drops the rest
+    std::vector<TreeCand> keep;
+    for (auto& c : cands)
+      if (c.depth <= stack_limit && (want.empty() || c.name == want || (want != "ref" && c.name == "ref" && cands.size() == 1))) keep.push_back(std::move(c));
+    if (keep.empty()) {
+      uint32_t dmin = 0xFFFFFFFFu;
+      for (auto& c : cands) if (c.wb) dmin = std::min(dmin, c.depth);
+      return sol_fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", dmin, stack_limit);
+    }
+    cands = std::move(keep);
+    // provisional choice by the surface-area estimate (it knows nothing of occlusion and visit order: the probe decides)
+    size_t best = 0;
+    for (size_t i = 1; i < cands.size(); ++i)
+      if (cands[i].wb->cost() < cands[best].wb->cost()) best = i;
+    std::swap(cands[0], cands[best]);
+  } else {  // the world is ONE primitive: a root with a single child
+    TreeCand c;
+    c.name = "ref";
+    c.wb.reset(new WideBuilder(tb.nodes, box_pad));
+    c.wb->set_exponent_range(root_box);
+    finish_cand(c, c.wb->build_single(root_ref, root_box));
+    if (!c.wb) return sol_fail(SOL_EINVAL, "world: %s", c.lay.error.c_str());
+    cands.push_back(std::move(c));
+  }
+  return SOL_OK;
+  };
+  // AUTO falls back to the host candidates when the device build cannot make a tree (a primitive with a non-finite or inverted box -
+  // e.g. a NaN vertex of an OBJ -, more than 2^23 primitives, no memory for its scratch): scenes the host path accepts are never
+  // refused by the default. An explicit SOL_TREE_DEVICE (or SOL_BVH=device) keeps the hard error.
+  const bool device_explicit = opt.world_tree == SOL_TREE_DEVICE || ovr.bvh == "device";
+  bool device_build = want == "device";
+  std::string fallback_note;
+  if (!device_build) { int rc0 = host_candidates(want); if (rc0) return rc0; }
+  double t_host_trees = seconds_since(t_begin);
+
+  // ---- lights ----
+  std::vector<uint32_t> lights(d->lights, d->lights + d->n_lights);
+  for (uint32_t i = 0; i < d->n_lights; ++i) {
+    uint32_t k = SOL_REF_KIND(lights[i]), x = SOL_REF_INDEX(lights[i]);
+    bool ok = (k == SOL_REF_SPHERE && x < d->n_spheres) || (k == SOL_REF_QUAD && x < d->n_quads) || (k == SOL_REF_TRIANGLE && x < d->n_triangles);
+    if (!ok) return sol_fail(SOL_EINVAL, "light %u: not a sphere/quad/triangle reference", i);
+  }
+
+  // ---- device ----
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sol_fail(SOL_EDEVICE, "no HIP device available");
+  if (device < 0 || device >= ndev) return sol_fail(SOL_EDEVICE, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  SolScene* s = new SolScene();
+  s->device = device;
+  s->build_times[0] = t_host_trees;
+  const auto t_upload0 = std::chrono::steady_clock::now();
+  struct Cleanup { SolScene* s; bool keep = false; ~Cleanup() { if (!keep) sol_scene_destroy(s); } } cleanup{s};
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  s->n_cu = prop.multiProcessorCount;
+  HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  s->stream = s->own_stream;
+  int rc;
+  if (device_build) {
+    const auto t_dev0 = std::chrono::steady_clock::now();
+    TreeCand c;
+    c.name = "device";
+    const uint32_t counts[3] = {d->n_triangles, d->n_spheres, d->n_quads};
+    rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, ovr.ploc_radius, s->stream, c.lay, c.emin);
+    if (!rc) {
+      c.depth = depth_of(c.lay);
+      if (c.depth > stack_limit) rc = sol_fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", c.depth, stack_limit);
+    }
+    s->build_times[2] = seconds_since(t_dev0);
+    if (!rc) {
+      cands.push_back(std::move(c));
+    } else if (device_explicit) {
+      return rc;
+    } else {
+      fallback_note = std::string("device build failed (") + sol_last_error() + "): host candidates";
+      if (ovr.verbose) std::fprintf(stderr, "[solstrale] world tree: %s\n", fallback_note.c_str());
+      device_build = false;
+      const auto t_host0 = std::chrono::steady_clock::now();
+      if ((rc = host_candidates(""))) return rc;
+      s->build_times[0] += seconds_since(t_host0);
+    }
+  }
+  const bool calibrate = cands.size() > 1 && !SOL_WORLD_BINARY && !device_build;
+  // everything that depends on the choice of the world tree: the tree itself, the permuted primitive arrays and every table of
+  // references into them (DevTree); candidate 0 first, the others only if a probe has to decide
+  const bool need_binary = SOL_WORLD_BINARY || d->n_mediums > 0;  // the 2-wide tree serves medium boundaries (and the A/B build) only
+  auto upload_tree = [&](TreeCand& c) -> int {
+    const WideLayout& L = c.lay;
+    DevTree& t = c.dev;
+    std::vector<DTri> ptris(tris.size());
+    std::vector<DTriShade> pshade(tshade.size());
+    std::vector<DQuad> pquads(quads.size());
+    std::vector<DSphere> pspheres(spheres.size());
+    for (size_t i = 0; i < tris.size(); ++i) { ptris[i] = tris[L.old_of_new[0][i]]; pshade[i] = tshade[L.old_of_new[0][i]]; }
+    for (size_t i = 0; i < spheres.size(); ++i) pspheres[i] = spheres[L.old_of_new[1][i]];
+    for (size_t i = 0; i < quads.size(); ++i) pquads[i] = quads[L.old_of_new[2][i]];
+    std::vector<DNode> pnodes;
+    if (need_binary) {
+      pnodes = tb.nodes;
+      for (auto& n : pnodes) { n.left = L.remap(n.left); n.right = L.remap(n.right); }
+    }
+    std::vector<DMedium> pmed = mediums;
+    for (auto& m : pmed) m.boundary = L.remap(m.boundary);
+    std::vector<uint32_t> plights = lights;
+    for (auto& r : plights) r = L.remap(r);
+    int e;
+    if ((e = sol_upload(L.nodes, &t.wides)) || (e = sol_upload(L.leaf_refs, &t.leaf_refs)) || (e = sol_upload(ptris, &t.tris)) || (e = sol_upload(pshade, &t.tri_shade)) ||
+        (e = sol_upload(pquads, &t.quads)) || (e = sol_upload(pspheres, &t.spheres)) || (e = sol_upload(pnodes, &t.nodes)) || (e = sol_upload(pmed, &t.mediums)) ||
+        (e = sol_upload(plights, &t.lights))) {
+      t.release();
+      return e;
+    }
+    t.emin = c.emin; t.depth = c.depth; t.root = L.remap(root_ref); t.light0 = plights.empty() ? 0u : plights[0];
+    t.old_tri = L.old_of_new[0]; t.old_sphere = L.old_of_new[1]; t.old_quad = L.old_of_new[2];
+    return SOL_OK;
+  };
+  auto adopt_tree = [&](DevTree& t) {  // the scene takes ownership
+    s->nodes = t.nodes; s->wides = t.wides; s->leaf_refs = t.leaf_refs; s->tris = t.tris; s->tri_shade = t.tri_shade; s->quads = t.quads;
+    s->spheres = t.spheres; s->mediums = t.mediums; s->lights = t.lights;
+    s->old_index[0] = std::move(t.old_tri); s->old_index[1] = std::move(t.old_sphere); s->old_index[2] = std::move(t.old_quad);
+    DevScene& S = s->S;
+    S.nodes = t.nodes; S.wides = t.wides; S.leaf_refs = t.leaf_refs; S.tris = t.tris; S.tri_shade = t.tri_shade; S.quads = t.quads; S.spheres = t.spheres;
+    S.mediums = t.mediums; S.lights = t.lights; S.light0 = t.light0; S.wroot = 0; S.wide_emin = t.emin; S.root = t.root;
+    s->tree_depth = t.depth;
+    t = DevTree{};
+  };
+  if ((rc = upload_tree(cands[0])) || (rc = sol_upload(mats, &s->mats)) || (rc = sol_upload(texs, &s->texs))) return rc;
+  {
+    std::vector<uint8_t> texels(d->texels, d->texels + d->n_texel_bytes);
+    if ((rc = sol_upload(texels, &s->texels))) return rc;
+  }
+  HIP_TRY(hipMalloc((void**)&s->work, 64));
+  HIP_TRY(hipMalloc((void**)&s->counters, sizeof(DevCounters)));
+  HIP_TRY(hipMemset(s->counters, 0, sizeof(DevCounters)));
+  HIP_TRY(hipMalloc((void**)&s->image, (size_t)d->width * d->height * 3 * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&s->rgb8, (size_t)d->width * d->height * 3));
+  s->build_times[1] = seconds_since(t_upload0) - s->build_times[2];
+  const auto t_probe0 = std::chrono::steady_clock::now();
+
+  DevScene& S = s->S;
+  S.mats = s->mats; S.texs = s->texs; S.texels = s->texels;
+  S.n_lights = d->n_lights;
+  adopt_tree(cands[0].dev);
+  S.rxmin = root_box.v[0]; S.rxmax = root_box.v[1]; S.rymin = root_box.v[2]; S.rymax = root_box.v[3];
+  S.rzmin = root_box.v[4]; S.rzmax = root_box.v[5];
+  S.width = d->width; S.height = d->height; S.shader = d->shader_kind; S.max_depth = d->max_depth;
+  S.sphere_slack = box_pad * 0.5f;
+  S.env = nullptr; S.env_w = S.env_h = 0; S.env_scale = 1.0f;
+  if (has_env) {
+    std::vector<float> env(d->env_texels, d->env_texels + (size_t)d->env_width * d->env_height * 3);
+    if ((rc = sol_upload(env, &s->env))) return rc;
+    S.env = s->env; S.env_w = d->env_width; S.env_h = d->env_height; S.env_scale = (float)d->env_scale;
+  }
+  S.bgx = (float)d->background[0]; S.bgy = (float)d->background[1]; S.bgz = (float)d->background[2];
+  const SolCamera& c = d->camera;
+  S.cam = DCamera{(float)c.origin[0], (float)c.origin[1], (float)c.origin[2],
+                  (float)c.lower_left_corner[0], (float)c.lower_left_corner[1], (float)c.lower_left_corner[2],
+                  (float)c.horizontal[0], (float)c.horizontal[1], (float)c.horizontal[2],
+                  (float)c.vertical[0], (float)c.vertical[1], (float)c.vertical[2],
+                  (float)c.u[0], (float)c.u[1], (float)c.u[2], (float)c.v[0], (float)c.v[1], (float)c.v[2],
+                  (float)c.lens_radius};
+  s->kernel_version = ovr.kernel_version;
+  s->order_mode = ovr.order_mode;
+  // v1's search/shade switch (RenderParams::switch_below), measured on MI355X at 1080p x 128 spp (ms, C1 / C2 / C3 / test scene):
+  // 0: 29.2 / 162.9 / 236.7 / 25.9, 8: 27.7 / 124.3 / 193.1 / 25.5, 16: 27.5 / 111.8 / 186.9 / 25.6, 24: 28.6 / 108.6 / 192.3 / 26.8.
+  s->switch_below = 16u;
+  if (ovr.switch_below >= 0) s->switch_below = (uint32_t)ovr.switch_below;
+  if (ovr.max_bpc >= 0) s->max_bpc = ovr.max_bpc;  // occupancy experiments
+  s->pool_slots_override = (uint32_t)ovr.pool_slots;
+  if (ovr.wf_slots > 0) s->wf_slots = (uint32_t)std::max(4096, ovr.wf_slots);
+  if (ovr.fine_tail >= -1) s->fine_tail = ovr.fine_tail;
+  if (ovr.wf_min_items >= 0) s->wf_min_items = (uint32_t)ovr.wf_min_items;
+  s->has_medium = d->n_mediums > 0;
+  s->blocks_x = (d->width + SOL_TILE - 1) / SOL_TILE;
+  s->blocks_y = (d->height + SOL_TILE - 1) / SOL_TILE;
+  if ((rc = sol_set_partition(s, 0, 1))) return rc;
+  {  // a null table would be a GPU memory fault at the first launch, not an error code: refuse here
+    const void* tables[] = {S.nodes, S.wides, S.leaf_refs, S.tris, S.tri_shade, S.quads, S.spheres, S.mediums, S.mats, S.texs, S.texels, S.lights};
+    for (const void* p : tables)
+      if (!p) return sol_fail(SOL_EDEVICE, "internal error: a device table of the scene is missing");
+  }
+  s->tree_name = cands[0].name;
+  s->tree_note = fallback_note;
+  if (calibrate) {
+    // Probe every candidate tree with a counted render of 16 samples per pixel over ~256 pixel blocks spread across the image
+    // and keep the one with the least search work (a wide-node visit weighs ~2.5 primitive tests, by instruction count).
+    // Images do not depend on the tree, the counters are deterministic, so is the choice.
+    auto free_cands = [&]() { for (auto& c : cands) c.dev.release(); };
+    for (size_t k = 1; k < cands.size(); ++k)
+      if ((rc = upload_tree(cands[k]))) { free_cands(); return rc; }
+    const uint32_t nb = s->blocks_x * s->blocks_y;
+    rc = sol_set_partition(s, 0, (int)std::max(1u, nb / 256u));
+    size_t pick = 0, current = 0;  // `current`: the candidate whose arrays the scene holds at the moment
+    auto swap_in = [&](size_t k) {  // hand the scene's tree back to its candidate, adopt candidate k's
+      if (k == current) return;
+      DevTree& back = cands[current].dev;
+      back.nodes = s->nodes; back.wides = s->wides; back.leaf_refs = s->leaf_refs; back.tris = s->tris; back.tri_shade = s->tri_shade;
+      back.quads = s->quads; back.spheres = s->spheres; back.mediums = s->mediums; back.lights = s->lights;
+      back.emin = S.wide_emin; back.depth = s->tree_depth; back.root = S.root; back.light0 = S.light0;
+      back.old_tri = std::move(s->old_index[0]); back.old_sphere = std::move(s->old_index[1]); back.old_quad = std::move(s->old_index[2]);
+      adopt_tree(cands[k].dev);
+      current = k;
+    };
+    for (size_t k = 0; k < cands.size() && !rc; ++k) {
+      swap_in(k);
+      if (!(rc = sol_clear(s)) && !(rc = sol_render_probe(s)))
+        cands[k].cost = 2.5 * (double)s->stats.node_visits + (double)(s->stats.sphere_tests + s->stats.quad_tests + s->stats.triangle_tests);
+      if (!rc && cands[k].cost < cands[pick].cost) pick = k;
+    }
+    if (ovr.verbose) {
+      std::fprintf(stderr, "[solstrale] world tree probe:");
+      for (auto& c : cands) std::fprintf(stderr, " %s %.4g (%zu nodes)", c.name.c_str(), c.cost, c.lay.nodes.size());
+      std::fprintf(stderr, " -> %s\n", cands[pick].name.c_str());
+    }
+    if (hipStreamSynchronize(s->stream) != hipSuccess && !rc) rc = SOL_EDEVICE;
+    swap_in(pick);
+    s->tree_name = cands[pick].name;
+    free_cands();
+    if (rc) return rc;
+    s->stats = SolStats{};
+    if ((rc = sol_set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  // Cost probe: per 8x8 block, the ray count of the longest 4-sample item in a counted render of the whole frame, for the
+  // heavy-first work order
+  // (rebuild_order; sol_path.h decode_item_ordered). SOL_ORDER=0 switches it off.
+  if (!opt.no_work_order_probe && ovr.order_mode != 0 && s->blocks_x * s->blocks_y >= 64u) {
+    const uint32_t nb = s->blocks_x * s->blocks_y;
+    uint32_t* cost_dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&cost_dev, (size_t)nb * sizeof(uint32_t)));
+    hipError_t e = hipMemset(cost_dev, 0, (size_t)nb * sizeof(uint32_t));
+    S.block_cost = cost_dev;
+    rc = e == hipSuccess ? sol_render_impl(s, 0, 4, 0xC057ull, true) : SOL_EDEVICE;
+    S.block_cost = nullptr;
+    s->block_cost.assign(nb, 0u);
+    if (rc == SOL_OK && hipMemcpy(s->block_cost.data(), cost_dev, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = SOL_EDEVICE;
+    hipFree(cost_dev);
+    if (rc != SOL_OK) return rc == SOL_EDEVICE ? sol_fail(SOL_EDEVICE, "cost probe failed") : rc;
+    // The fine tail takes an item fetch per SAMPLE (a dependent load, three integer divisions: ~2 us): worth it where a sample
+    // is long. MI355X, 1080p x 64 spp, ms with 0 / 1 / 2 whole items per lane in the tail: C3 (38 node visits per sample) 76.5 /
+    // 75.5 / 74.4, C2 (22) 45.5 / 45.7 / 46.3, C1 (2) 10.5 / 11.2 / 11.8.
+    if (s->stats.samples > 0) {
+      const double vps = (double)s->stats.node_visits / (double)s->stats.samples;
+      s->fine_tail_auto = vps >= 30.0 ? 8 : 0;
+    }
+    s->stats = SolStats{};
+    if ((rc = sol_clear(s)) || (rc = sol_rebuild_order(s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (ovr.verbose) std::fprintf(stderr, "[solstrale] work order: %u of %u blocks heavy (first)\n", S.n_first, s->n_local_blocks);
+  }
+  s->build_times[3] = seconds_since(t_probe0);
+  cleanup.keep = true;
+  *out = s;
+  return SOL_OK;
+}
+
+int sol_scene_build_times(const SolScene* s, double out[4]) {
+  if (!s || !out) return sol_fail(SOL_EINVAL, "null argument");
+  for (int k = 0; k < 4; ++k) out[k] = s->build_times[k];
+  return SOL_OK;
+}
+
+}  // extern "C"

@@ -181,6 +181,7 @@ hipError_t sol_launch_stage_resolve(const DevScene* dS, const RenderParams& P, f
   return hipGetLastError();
 }
 
+#ifdef SOL_AB_KERNELS
 // ---------------------------------------------------------------------------------------------------------------------------
 // v2: wave-private wavefront over a pool of path slots
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -359,6 +360,8 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
   if (COUNT) flush_counters(cnt, dcnt);
 }
 
+#endif  // SOL_AB_KERNELS
+
 // Diagnostic: one path (pixel, sample) on one lane, every ray and its closest hit recorded: 12 floats per ray
 // (origin, direction, t, ref bits, dfs bits, depth, 0, 0), then a terminator row (colour in the first 3 floats, -1 in the 4th).
 template <bool MEDIUM>
@@ -410,6 +413,7 @@ static hipError_t launch_v1(const DevScene* dS, const RenderParams& P, float* ac
   hipLaunchKernelGGL((sol_render_kernel<COUNT, MEDIUM, SPILL>), dim3(grid), dim3(SOL_WG), 0, stream, dS, P, acc, partial, work, spill, cnt);
   return hipGetLastError();
 }
+#ifdef SOL_AB_KERNELS
 template <bool COUNT, bool MEDIUM>
 static hipError_t launch_v2(const DevScene& S, const RenderParams& P, float* acc, float* partial, uint32_t* work,
                             uint32_t* spill, float4* pool, DevCounters* cnt, uint32_t grid, hipStream_t stream) {
@@ -417,6 +421,7 @@ static hipError_t launch_v2(const DevScene& S, const RenderParams& P, float* acc
                      pool, cnt);
   return hipGetLastError();
 }
+#endif
 
 hipError_t sol_launch_render(int version, const DevScene& S, const DevScene* dS, const RenderParams& P, float* acc, float* partial, uint32_t* work,
                              uint32_t* spill, void* pool, DevCounters* cnt, uint32_t grid, bool count, bool medium, bool may_spill,
@@ -429,11 +434,15 @@ hipError_t sol_launch_render(int version, const DevScene& S, const DevScene* dS,
     return medium ? launch_v1<false, true, false>(dS, P, acc, partial, work, spill, cnt, grid, stream)
                   : launch_v1<false, false, false>(dS, P, acc, partial, work, spill, cnt, grid, stream);
   }
+#ifdef SOL_AB_KERNELS
   float4* pl = (float4*)pool;
   if (count) return medium ? launch_v2<true, true>(S, P, acc, partial, work, spill, pl, cnt, grid, stream)
                            : launch_v2<true, false>(S, P, acc, partial, work, spill, pl, cnt, grid, stream);
   return medium ? launch_v2<false, true>(S, P, acc, partial, work, spill, pl, cnt, grid, stream)
                 : launch_v2<false, false>(S, P, acc, partial, work, spill, pl, cnt, grid, stream);
+#else
+  return hipErrorInvalidValue;  // (the wavefront variants are A/B builds: -DSOL_AB_KERNELS)
+#endif
 }
 
 template <typename K>
@@ -447,7 +456,13 @@ int sol_render_blocks_per_cu(int version, bool count, bool medium) {
     if (count) return medium ? blocks_per_cu(sol_render_kernel<true, true, true>) : blocks_per_cu(sol_render_kernel<true, false, true>);
     return medium ? blocks_per_cu(sol_render_kernel<false, true, true>) : blocks_per_cu(sol_render_kernel<false, false, true>);
   }
+#ifdef SOL_AB_KERNELS
   if (count) return medium ? blocks_per_cu(sol_render_pool_kernel<true, true>) : blocks_per_cu(sol_render_pool_kernel<true, false>);
   return medium ? blocks_per_cu(sol_render_pool_kernel<false, true>) : blocks_per_cu(sol_render_pool_kernel<false, false>);
+#else
+  return 1;
+#endif
 }
+#ifdef SOL_AB_KERNELS
 size_t sol_pool_bytes_per_wave(uint32_t slots) { return (size_t)POOL_RECORDS * slots * sizeof(float4); }
+#endif

@@ -170,7 +170,7 @@ struct WideBuilder {
   uint32_t max_depth = 0;
   // surface-area estimate of a random ray's work: summed box areas of the children that are wide nodes / primitives
   // (a child is visited with probability ~ its area / the root's area)
-  bool slot_by_assignment = !(std::getenv("SOL_SLOTS") && std::strcmp(std::getenv("SOL_SLOTS"), "octant") == 0);
+  bool slot_by_assignment = true;  // false (SOL_SLOTS=octant): children by the octant of their centre alone
   double inner_area = 0., leaf_area = 0.;
   double cost() const { return 2.5 * inner_area + leaf_area; }  // a wide-node visit costs ~2.5 primitive tests (instructions)
   struct Child { uint32_t ref; Box box; };
@@ -183,6 +183,9 @@ struct WideBuilder {
   static float area(const Box& b) {
     float dx = b.v[1] - b.v[0], dy = b.v[3] - b.v[2], dz = b.v[5] - b.v[4];
     if (!(dx >= 0.f && dy >= 0.f && dz >= 0.f)) return 0.f;
+    // an unbounded box (a primitive whose fp32 coordinates overflow) counts as a very large one: with an infinite area every
+    // comparison of the collapse's cost table is false and whole sub-trees would silently drop out of the wide tree
+    dx = std::min(dx, 1e15f); dy = std::min(dy, 1e15f); dz = std::min(dz, 1e15f);
     return dx * dy + dy * dz + dz * dx;
   }
   static float decode(float origin, uint32_t q, float scale) { return origin + (float)q * scale; }  // == device decode
@@ -196,7 +199,7 @@ struct WideBuilder {
   //   sub-trees near the leaves as wide nodes with two or three children: C3 has 92 075 nodes of 3.85 children on average
   //   under it and 51 567 of 6.09 under the DP; node visits per ray 12.9 -> 11.9 (C3), 9.8 -> 9.5 (C2), time -0.5 .. -3 %.
   bool dp_collapse = true;   // SOL_COLLAPSE=greedy selects the other rule (A/B)
-  double NODE_COST = std::getenv("SOL_NODE_COST") ? std::atof(std::getenv("SOL_NODE_COST")) : 2.5;  // (experiment knob)
+  double NODE_COST = 2.5;    // (experiment knob: SOL_NODE_COST)
   static constexpr double PRIM_COST = 1.0;
   struct Dp { double c[9]; uint8_t eff[9], split[9]; bool done = false; };
   std::vector<Dp> dp;

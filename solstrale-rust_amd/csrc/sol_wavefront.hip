@@ -15,6 +15,7 @@
 //                         waves per SIMD (SOL_WF_MIN_WAVES) against the product kernel's 4.
 // The first version of this design issued one global atomic per 16 rays on one address and ran at the chip's single-address
 // atomic rate (about 88 M/s) instead of the traversal rate - the lesson behind the product kernel's item reservoir.
+#ifdef SOL_AB_KERNELS  // an A/B variant: not part of the product library (build.py)
 #include <hip/hip_runtime.h>
 
 #include "sol_launch.h"
@@ -284,3 +285,4 @@ int sol_wf_trace_blocks_per_cu(bool count, bool medium) {
 }
 size_t sol_wf_pool_bytes(uint32_t slots) { return (size_t)POOL_RECORDS * slots * sizeof(float4); }
 int sol_wf_lds_stack_depth() { return SOL_LDS_STACK_TRACE; }
+#endif  // SOL_AB_KERNELS

@@ -106,6 +106,14 @@ class DeviceScene:
         self._chk(self.lib.sol_scene_build_times(self.h, out))
         return dict(zip(("host_trees", "upload", "device_tree", "probes"), [float(x) for x in out]))
 
+    def info(self):
+        """sol_scene_info: the world tree in use (and why, when it is not the one asked for), the bound on the traversal stack."""
+        r = _abi.SolSceneInfo()
+        r.size = C.sizeof(r)
+        self._chk(self.lib.sol_scene_info(self.h, C.byref(r)))
+        return {"stack_bound": int(r.stack_bound), "lds_stack": int(r.lds_stack), "spill_stack": int(r.spill_stack),
+                "tree_fallback": bool(r.tree_fallback), "tree_name": r.tree_name.decode(), "tree_note": r.tree_note.decode()}
+
     def max_samples_per_call(self):
         return int(self.lib.sol_max_samples_per_call(self.h))
 

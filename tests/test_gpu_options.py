@@ -33,11 +33,11 @@ def test_scheduler_options_do_not_change_the_frame():
     with DeviceScene(sc) as ds:
         want = _frame(ds)
         for opt, values in ((_abi.OPT_SWITCH_BELOW, (0, 8, 40, 64)), (_abi.OPT_MAX_BLOCKS_PER_CU, (1, 2, 0)), (_abi.OPT_WORK_ORDER, (0, 1)),
-                            (_abi.OPT_FINE_TAIL, (0, 4, 64, -1)), (_abi.OPT_KERNEL, (2, 3, 1, 0))):
+                            (_abi.OPT_FINE_TAIL, (0, 4, 64, -1)), (_abi.OPT_KERNEL, (1, 0))):
             for v in values:
                 ds.set_option(opt, v)
                 assert (_frame(ds) == want).all(), (opt, v)
-        for opt, v in ((_abi.OPT_SWITCH_BELOW, 65), (_abi.OPT_SWITCH_BELOW, -1), (_abi.OPT_KERNEL, 4), (_abi.OPT_FINE_TAIL, -2), (_abi.OPT_FINE_TAIL, 65), (99, 0)):
+        for opt, v in ((_abi.OPT_SWITCH_BELOW, 65), (_abi.OPT_SWITCH_BELOW, -1), (_abi.OPT_KERNEL, 4), (_abi.OPT_KERNEL, 2), (_abi.OPT_FINE_TAIL, -2), (_abi.OPT_FINE_TAIL, 65), (99, 0)):
             with pytest.raises(DeviceError) as e:
                 ds.set_option(opt, v)
             assert e.value.code == _abi.SOL_EINVAL
@@ -108,3 +108,60 @@ def test_rebinding_rules_of_a_caller_bound_accumulator():
         ds.set_partition(1, 2)
         ds.render(0, 4, pu.SEED)
         assert np.isfinite(ds.read()).all()
+
+
+def _scene_with_an_unbounded_triangle():
+    """One triangle has a vertex at 1e39: finite in f64, infinite as fp32 - its device box cannot be collected by the GPU builder
+    (nor by the SAH rebuilds); the collapsed reference tree holds it as a box no finite ray parameter reaches."""
+    import orc  # noqa: F401  (the checker of the frames below)
+    from solstrale_amd import CameraConfig, SceneBuilder
+    b = SceneBuilder()
+    white = b.Lambertian(b.SolidColor(.7, .7, .7))
+    world = [b.Quad((-3., 0., -3.), (6., 0, 0), (0, 0, 6.), white), b.Sphere((0., 1., 0.), 1., white),
+             b.Triangle((1e39, 0., 0.), (1., 0., 0.), (0., 1., 0.), white), b.Triangle((-1., 0., 1.), (1., 0., 1.), (0., 2., 1.), white),
+             b.Sphere((0., 8., 0.), 2., b.DiffuseLight(5, 5, 5))]
+    return b.finish(b.Bvh(world), CameraConfig(40., 0., (0., 2., 7.), (0., 1., 0.), (0, 1, 0)), (.2, .3, .4), RenderConfig(64, 48, 4))
+
+
+def test_auto_tree_falls_back_when_the_device_build_cannot_make_a_tree():
+    """SOL_TREE_AUTO is the GPU build; a scene it cannot handle (here: a primitive whose fp32 box is not finite) must still be
+    accepted by the default path - as the host path accepts it - through the host candidates, and SolSceneInfo says so. An
+    explicit SOL_TREE_DEVICE keeps the error."""
+    import orc
+    sc = _scene_with_an_unbounded_triangle()
+    with DeviceScene(sc) as ds:  # defaults
+        info = ds.info()
+        assert info["tree_fallback"] and info["tree_name"] == "ref" and "device build failed" in info["tree_note"], info
+        img = _frame(ds, 4)
+    ref, _ = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F32)
+    assert pu.compare(img, ref, 4)["bad_pixels"] == 0
+    with DeviceScene(sc, world_tree=_abi.TREE_REF) as ds:
+        assert not ds.info()["tree_fallback"] and (_frame(ds, 4) == img).all()
+    with pytest.raises(DeviceError) as e:
+        DeviceScene(sc, world_tree=_abi.TREE_DEVICE)
+    assert "collected" in str(e.value)
+    with DeviceScene(scenes.cornell_box(RenderConfig(32, 32, 1))) as ds:  # an ordinary scene: no fallback
+        info = ds.info()
+        assert not info["tree_fallback"] and info["tree_name"] == "device" and info["tree_note"] == ""
+
+
+def test_stack_use_stays_within_the_bound_the_kernel_choice_relies_on():
+    """The render kernel without a spill path is chosen from the host's bound on the stack use (SolSceneInfo.stack_bound <=
+    lds_stack): in that variant an overflow would silently overwrite other lanes' stacks. A counted render measures the deepest
+    use; it must stay within the bound - on the BASELINE scenes, on a scene with a constant medium, and on a deep chain."""
+    import test_gpu_parity as tgp
+    from solstrale_amd import CameraConfig, SceneBuilder
+    cases = [scenes.cornell_box(RenderConfig(96, 96, 4)), scenes.cornell_spheres(RenderConfig(160, 90, 4)), scenes.sponza_like(RenderConfig(160, 90, 4)),
+             scenes.statue_like(RenderConfig(160, 90, 4)), scenes.create_test_scene(RenderConfig(160, 80, 4))]
+    b = SceneBuilder()
+    chain = tgp._sphere_chain(b)
+    light = b.Sphere((0., 1e4, 0.), 3e3, b.DiffuseLight(3, 3, 3))
+    cases.append(b.finish(b.Bvh([chain, light]), CameraConfig(12., 0., (-30., 0.4, 0.3), (50., 0.3, 0.), (0, 1, 0)), (.1, .1, .1), RenderConfig(64, 64, 4)))
+    for sc in cases:
+        for tree in (_abi.TREE_AUTO, _abi.TREE_REF):
+            with DeviceScene(sc, world_tree=tree) as ds:
+                info = ds.info()
+                ds.render(0, 4, pu.SEED, counted=True)
+                st = ds.stats()
+            assert st["max_stack"] <= info["stack_bound"], (tree, st["max_stack"], info)  # (0: a one-node tree never pushes)
+            assert info["stack_bound"] <= info["lds_stack"] + info["spill_stack"]

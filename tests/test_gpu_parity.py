@@ -59,12 +59,12 @@ def test_c3_sponza_class_crop():
 
 
 @pytest.mark.parametrize("env", [{"SOL_BVH": "ref"}, {"SOL_BVH": "sah"}, {"SOL_SWITCH": "0"}, {"SOL_SWITCH": "40"},
-                                 {"SOL_BVH": "sah", "SOL_SLOTS": "octant"}, {"SOL_KERNEL": "v2"}, {"SOL_KERNEL": "v3"}],
+                                 {"SOL_BVH": "sah", "SOL_SLOTS": "octant"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_tree_and_schedule_variants_are_bit_identical(env, monkeypatch):
     """The closest hit does not depend on the tree (reference topology, SAH rebuild, slot assignment), and the image is a
-    pure function of (scene, seed): every world-tree choice, every search/shade switch threshold and every kernel variant
-    must reproduce the default build's frame bit for bit ("tree independence")."""
+    pure function of (scene, seed): every world-tree choice and every search/shade switch threshold must reproduce the default
+    build's frame bit for bit ("tree independence"; the kernel variants: test_wavefront_ab_kernels_are_bit_identical)."""
     frames = {}
     for name, make in (("c2", scenes.cornell_spheres), ("c3", scenes.sponza_like)):
         sc = make(RenderConfig(480, 270, 16))
@@ -74,6 +74,34 @@ def test_tree_and_schedule_variants_are_bit_identical(env, monkeypatch):
     for name, (sc, want) in frames.items():
         got = gpu_render(sc, 16)
         assert (got == want).all(), (name, env, int((got != want).sum()))
+
+
+def test_wavefront_ab_kernels_are_bit_identical():
+    """The staged wavefront forms of the path (north star: "ballot/prefix compaction of active-ray queues into generate /
+    intersect / shade stages") live in the A/B build of the library only (_build_ab/, -DSOL_AB_KERNELS: kernel 2 = wave-private
+    pool with an LDS ray queue, 3 = separate shade and trace kernels): measured slower than the in-register search/service switch
+    of the product kernel, kept as variants. Their frames, and the A/B library's own kernel 1, must equal the
+    product library's frames bit for bit; the product library itself refuses 2 and 3."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import frame_crc
+    want = frame_crc.crcs([1])
+    ab_dir = os.path.join(os.path.dirname(_abi.BUILD_DIR), "_build_ab")
+    assert os.path.exists(os.path.join(ab_dir, "libsolstrale_hip.so")), "the A/B library is missing: __graft_entry__.build() makes it"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "frame_crc.py"), "1", "2", "3"],
+                       env=dict(os.environ, SOLSTRALE_BUILD_DIR=ab_dir), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    for key, crc in got.items():
+        assert crc == want[key.split("/")[0] + "/1"], (key, got, want)
+    assert len(got) == 3 * len(want)
+    with DeviceScene(scenes.cornell_box(RenderConfig(16, 16, 1))) as ds:
+        for k in (2, 3):
+            with pytest.raises(DeviceError) as e:
+                ds.set_option(_abi.OPT_KERNEL, k)
+            assert e.value.code == _abi.SOL_EINVAL and "SOL_AB_KERNELS" in str(e.value)
 
 
 def test_device_built_tree_renders_the_same_frames():
