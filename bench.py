@@ -8,7 +8,9 @@ A "step" is one pass of the hot path over one frame of synthetic input: the C3 w
     accumulators travel to rank 0 over RCCL/xGMI inside the C ABI; then the un-permute into the row-major image).
 N ranks (one process per GPU) shard the 8x8-pixel tiles of the frame round-robin. `python bench.py --gpus N` starts its own
 N rank processes (before any GPU call; a failed rank makes the run exit non-zero); under torch.distributed.run
-(RANK/WORLD_SIZE in the environment) it is one of the ranks. Two scaling modes:
+(RANK/WORLD_SIZE in the environment) it is one of the ranks. The ONLY communicator is the one the C ABI owns (sol_comm_init);
+the ranks' rendezvous - the 128-byte id, the barriers around the timed region, the max-over-ranks time - goes through a
+key-value store (the parent's socket, or the launcher's TCPStore), not through a second RCCL process group. Two scaling modes:
   --scaling strong (default: the metric's own definition - the SAME 1080p x 512 spp job on 1/2/4/8 GPUs): total work fixed;
   --scaling weak: per-GPU work fixed (512*N spp on the shared frame).
 `value` is the whole-job aggregate Msamples/s = W*H*spp_total / step time (max over ranks).
@@ -28,11 +30,13 @@ import csv
 import glob
 import json
 import os
+import pickle
 import shutil
 import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -86,27 +90,152 @@ def parse_args():
     ap.add_argument("--pmc-spp", type=int, default=64)
     ap.add_argument("--no-build", action="store_true", help="do not run the build step (use under rocprofv3: no child processes)")
     ap.add_argument("--rehearse", action="store_true",
-                    help="N>1 dry run on a box with ONE GPU: every rank uses cuda:0, the gather goes through gloo on host "
-                         "copies (RCCL refuses two ranks on one device); exercises partition, gather protocol and un-permute, "
-                         "its throughput means nothing and the JSON line says so")
+                    help="N>1 dry run on a box with ONE GPU: every rank uses cuda:0 and goes through the same sol_comm_init / "
+                         "sol_gather calls as a real run, over the test-only transport stub tests/stub_rccl (RCCL refuses two "
+                         "ranks on one device); its throughput means nothing and the JSON line says so")
     return ap.parse_args()
+
+
+# ---- rendezvous of the ranks: a tiny key-value store (set / blocking get / add) ------------------------------------------------
+class _StoreServer(threading.Thread):
+    """The parent of self-launched ranks serves the store on a socket it binds BEFORE the ranks start and keeps open."""
+
+    def __init__(self):
+        super().__init__(daemon=True)
+        self.sock = socket.socket()
+        self.sock.bind(("127.0.0.1", 0))
+        self.sock.listen(64)
+        self.port = self.sock.getsockname()[1]
+        self.data, self.cv = {}, threading.Condition()
+
+    def run(self):
+        while True:
+            try:
+                conn, _ = self.sock.accept()
+            except OSError:
+                return
+            threading.Thread(target=self.serve, args=(conn,), daemon=True).start()
+
+    def serve(self, conn):
+        f = conn.makefile("rwb")
+        try:
+            while True:
+                try:
+                    op, key, val = pickle.load(f)
+                except EOFError:
+                    return
+                with self.cv:
+                    if op == "set":
+                        self.data[key] = val
+                        self.cv.notify_all()
+                        out = None
+                    elif op == "add":
+                        out = self.data[key] = self.data.get(key, 0) + val
+                        self.cv.notify_all()
+                    else:  # get: blocks until the key exists
+                        self.cv.wait_for(lambda: key in self.data)
+                        out = self.data[key]
+                pickle.dump(out, f)
+                f.flush()
+        except (OSError, pickle.PickleError):
+            return
+
+
+class _SockStore:
+    def __init__(self, host, port):
+        self.f = socket.create_connection((host, port), timeout=600).makefile("rwb")
+
+    def _call(self, op, key, val=None):
+        pickle.dump((op, key, val), self.f)
+        self.f.flush()
+        return pickle.load(self.f)
+
+    def set(self, key, val):
+        self._call("set", key, val)
+
+    def get(self, key):
+        return self._call("get", key)
+
+    def add(self, key, n):
+        return self._call("add", key, n)
+
+
+class _TorchStore:
+    """Under torch.distributed.run: the launcher's TCPStore (c10d key-value store; no process group, no RCCL)."""
+
+    def __init__(self, rank, world):
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        host, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"  # the agent already serves MASTER_PORT
+        self.s = TCPStore(host, port, world, is_master=(rank == 0 and not agent), timeout=timedelta(seconds=600), wait_for_workers=False)
+
+    def set(self, key, val):
+        self.s.set("solbench/" + key, pickle.dumps(val))
+
+    def get(self, key):
+        self.s.wait(["solbench/" + key])
+        return pickle.loads(self.s.get("solbench/" + key))
+
+    def add(self, key, n):
+        return int(self.s.add("solbench/" + key, n))
+
+
+class Coord:
+    """What the ranks need from each other outside the data path: one broadcast of bytes, barriers, the maximum of a float."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.n = rank, world, 0
+        self.store = None
+        if world > 1:
+            self.store = _SockStore(*os.environ["SOLBENCH_STORE"].rsplit(":", 1)) if os.environ.get("SOLBENCH_STORE") else _TorchStore(rank, world)
+
+    def _next(self, what):
+        self.n += 1
+        return f"{what}{self.n}"
+
+    def bcast(self, data=None):
+        if self.world == 1:
+            return data
+        key = self._next("bcast")
+        if self.rank == 0:
+            self.store.set(key, data)
+        return self.store.get(key)
+
+    def barrier(self):
+        if self.world == 1:
+            return
+        key = self._next("barrier")
+        if self.store.add(key, 1) == self.world:
+            self.store.set(key + "/open", True)
+        self.store.get(key + "/open")
+
+    def max(self, x):
+        if self.world == 1:
+            return x
+        key = self._next("max")
+        self.store.set(f"{key}/{self.rank}", float(x))
+        return max(self.store.get(f"{key}/{r}") for r in range(self.world))
 
 
 # ---- N > 1 without a launcher: this process becomes the parent of N rank processes ----------------------------------------
 def launch_ranks(args):
     """Starts N copies of this script, one per GPU, BEFORE anything here touches the GPU. Rank 0 prints the JSON line (its
-    stdout is ours); any rank failing fails the run (the others are terminated: a lost rank would hang their collectives)."""
+    stdout is ours); any rank failing fails the run (the others are terminated: a lost rank would hang their collective)."""
     if not args.no_build:
         import __graft_entry__
         __graft_entry__.build()  # once, here: the ranks must not race on the build (compiles and dlopens only, no GPU call)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    server = _StoreServer()  # (the listening socket exists from here on: no port to lose between choosing and using it)
+    server.start()
+    extra = {}
+    if args.rehearse:  # the one-GPU transport stub in front of the real librccl.so.1, for the rank processes only
+        stub = os.path.join(ROOT, "tests", "stub_rccl")
+        subprocess.check_call(["make", "-s", "-C", stub])
+        extra["LD_LIBRARY_PATH"] = os.path.join(stub, "_build") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", "")
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   SOLBENCH_STORE=f"127.0.0.1:{server.port}", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--no-build"] + ["--no-build"]
         procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
     rc = 0
@@ -211,35 +340,35 @@ def make_scene(args, spp_total):
 
 
 def worker(args):
-    import torch
     import __graft_entry__
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse and world > 1 and not os.environ.get("SOLBENCH_STORE"):
+        raise SystemExit("--rehearse is started by bench.py itself (python bench.py --gpus N --rehearse): its ranks need the transport stub on "
+                         "LD_LIBRARY_PATH and must not load torch's RCCL")
+    # torch is here for device memory, the stream and the synchronisation of the timed region; the rehearsal's ranks do without
+    # it (importing torch loads torch's own RCCL, which the product's dlopen would then hand back instead of the stub)
+    torch = None
+    if not args.rehearse:
+        import torch
     if rank == 0 and not args.no_build:
         __graft_entry__.build()
-    import torch.distributed as dist
-    if args.rehearse:
-        local_rank = 0
-    rccl_ranks = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if args.rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            rccl_ranks = dist.get_world_size()
-        dist.barrier()
+    coord = Coord(rank, world)
+    coord.barrier()
     if rank != 0 and not args.no_build:
         __graft_entry__.build()  # no-op when up to date; loads the libraries
-    from solstrale_amd import DeviceScene, RenderConfig, comm_unique_id, device_count, record_sizes, tiles
+    if args.rehearse:
+        local_rank = 0
+    from solstrale_amd import DeviceScene, RenderConfig, comm_unique_id, device_count, record_sizes
     if device_count() < 1:
         raise SystemExit("bench.py: no HIP device; the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = None
+    if torch is not None:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
     w, h, spp0, name, make = make_scene(args, 0)
     spp_arg = args.spp or spp0
@@ -251,20 +380,22 @@ def worker(args):
     ds = DeviceScene(scene, local_rank)
     t_upload = time.time() - t0
     bt = ds.build_times()
-    stream = torch.cuda.current_stream(dev)
-    ds.set_stream(stream.cuda_stream)
-    use_abi_gather = world > 1 and not args.rehearse
-    if use_abi_gather:
-        # the communicator lives behind the C ABI (sol_comm_init); torch.distributed only ships the 128-byte id
-        box = [comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ds.comm_init(rank, world, box[0])
-    else:
-        ds.set_partition(rank, world)
-    n_acc = ds.accum_floats()
-    acc = torch.zeros(n_acc, dtype=torch.float32, device=dev)
-    ds.bind_accum(acc.data_ptr(), n_acc)
-    image = torch.empty(h * w * 3, dtype=torch.float32, device=dev) if rank == 0 else None
+    rccl_ranks = None
+    if world > 1:
+        # the ONE communicator of the run lives behind the C ABI (sol_comm_init: ncclCommInitRank); the store only ships the id
+        uid = coord.bcast(bytes(comm_unique_id()) if rank == 0 else None)
+        ds.comm_init(rank, world, uid)
+        rccl_ranks = world
+    acc = image = None
+    image_ptr = 0  # (0: the scene's own image buffer)
+    if torch is not None:
+        ds.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        n_acc = ds.accum_floats()
+        acc = torch.zeros(n_acc, dtype=torch.float32, device=dev)
+        ds.bind_accum(acc.data_ptr(), n_acc)
+        if rank == 0:
+            image = torch.empty(h * w * 3, dtype=torch.float32, device=dev)
+            image_ptr = image.data_ptr()
     ds.kernel_timing(True)
     max_spp_call = max(16, ds.max_samples_per_call() // 16 * 16)  # a sol_render call handles < 2^32 work items
 
@@ -275,22 +406,14 @@ def worker(args):
             n = min(spp - f, max_spp_call)
             ds.render(f, n, SEED)
             f += n
-        if use_abi_gather:
-            ds.gather(image.data_ptr() if rank == 0 else 0)
-        elif world > 1:  # rehearsal: gloo through host copies
-            torch.cuda.synchronize(dev)
-            g = tiles.gather_to_rank0(acc.cpu(), world, rank)
-            if rank == 0:
-                gathered = g.to(dev)
-                ds.unpermute(gathered.data_ptr(), world, image.data_ptr())
-                torch.cuda.synchronize(dev)
-        else:
-            ds.gather(image.data_ptr())
+        ds.gather(image_ptr)  # N > 1: collective (grouped ncclSend / ncclRecv into rank 0); always the un-permute on rank 0
 
     def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        coord.barrier()
+        if torch is not None:
+            torch.cuda.synchronize(dev)
+        else:
+            ds.sync()
 
     for _ in range(args.warmup):
         step()
@@ -299,16 +422,14 @@ def worker(args):
     for _ in range(args.steps):
         step()
     fence()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (args.rehearse or world == 1) else dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = coord.max(time.perf_counter() - t0)
     k_ms, grid = ds.last_kernel_ms()  # duration of the last step's (last) render kernel (HIP events on its stream)
     last_call_spp = spp - (spp - 1) // max_spp_call * max_spp_call
 
     # ---- counters: exact per-sample algorithmic bytes and rays from a counter-enabled run of the same kernels ----
-    ds.bind_accum(0, 0)
+    frame = ds.read_image() if (rank == 0 and args.rehearse) else None  # the gathered frame of the last step
+    if torch is not None:
+        ds.bind_accum(0, 0)
     ds.kernel_timing(False)
     c_spp = min(16, spp)
     ds.clear()
@@ -333,8 +454,8 @@ def worker(args):
             "config": {"workload": name, "width": w, "height": h, "spp_total": spp, "pixel_samples_per_gpu": int(w * h * spp // world),
                        "seed": SEED, "max_depth": 50, "scaling_mode": args.scaling,
                        "sharding": f"8x8 tiles round-robin over {world} rank(s); every rank renders its tiles with all {spp} spp; "
-                                   f"gather to rank 0 " + ("inside the C ABI (sol_gather: grouped ncclSend/ncclRecv)" if use_abi_gather else
-                                                           "(rehearsal: gloo)" if world > 1 else "(single rank: un-permute only)")},
+                                   f"gather to rank 0 " + ("inside the C ABI (sol_gather: grouped ncclSend/ncclRecv)" + (" over the one-GPU test transport stub" if args.rehearse else "")
+                                                           if world > 1 else "(single rank: un-permute only)")},
             "mrays_per_s": round(value * rays_per_sample, 2),
             "rays_per_sample": round(rays_per_sample, 4),
             "rays_per_sample_note": "the open-roofed atrium ends most paths on the sky after ~3 rays; a closed interior costs several "
@@ -353,14 +474,17 @@ def worker(args):
         if world > 1:
             out["rccl_ranks"] = rccl_ranks
         if args.rehearse:
-            out["rehearsal"] = "all ranks on cuda:0, gloo gather through host copies: not a measurement"
-            # the assembled frame must equal what one rank renders alone (the image is a pure function of scene and seed)
+            out["rehearsal"] = "all ranks on cuda:0, sol_gather over the test-only transport stub (tests/stub_rccl): not a measurement"
+    if args.rehearse and world > 1:
+        # the assembled frame must equal what one rank renders alone (the image is a pure function of scene and seed)
+        coord.barrier()
+        ds.comm_destroy()
+        if rank == 0:
+            import numpy as np
             ds.set_partition(0, 1)
             ds.clear()
-            ds.render(0, min(spp, 64), SEED)
-            single = torch.from_numpy(ds.read()).to(dev).reshape(-1)
-            ds.set_partition(rank, world)
-            out["rehearsal_frame_check"] = "skipped (spp > 64)" if spp > 64 else bool(torch.equal(single, image))
+            ds.render(0, spp, SEED)
+            out["rehearsal_frame_check"] = bool(np.array_equal(ds.read(), frame))
     ds.close()
     del ds
     if rank == 0 and world == 1 and not args.no_pmc:
@@ -411,9 +535,7 @@ def worker(args):
                                              f"reference algorithm (reference-order BVH search, no culling), row-parallel std::thread",
                                    "mrays_per_s": round(ost["rays"] / tc / 1e6, 3), "gpu_over_cpu": round(value / cpu_v, 1)}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    coord.barrier()
 
 
 def main():

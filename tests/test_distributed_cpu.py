@@ -81,3 +81,55 @@ def test_compact_roundtrip():
     for world in (1, 2, 5):
         g = np.concatenate([tiles.compact_from_image(img, r, world) for r in range(world)])
         assert (tiles.image_from_gathered(g, 45, 27, world) == img).all()
+
+
+# ---- bench.py's rendezvous of the ranks (outside the data path): no process group, no second communicator -------------------
+def _run_coord_ranks(world, env_of):
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "coord_check.py")
+    procs = [subprocess.Popen([sys.executable, script], env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), **env_of(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0 and f"rank {r}/{world} ok" in outs[r], outs[r][-1500:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_rendezvous_through_the_parents_socket(world):
+    """`python bench.py --gpus N`: the parent binds the store's socket before it starts the ranks and serves set / get / add."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    server = bench._StoreServer()
+    server.start()
+    _run_coord_ranks(world, lambda r: {"SOLBENCH_STORE": f"127.0.0.1:{server.port}"})
+    server.sock.close()
+
+
+def test_bench_rendezvous_through_a_tcpstore():
+    """Under torch.distributed.run the ranks find MASTER_ADDR / MASTER_PORT: a c10d TCPStore (rank 0 serves it unless the launcher's
+    agent already does), still no process group."""
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ("SOLBENCH_STORE", "TORCHELASTIC_USE_AGENT_STORE")}
+    os_env = dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    saved = dict(os.environ)
+    try:
+        os.environ.clear()
+        os.environ.update(env)
+        _run_coord_ranks(2, lambda r: os_env)
+    finally:
+        os.environ.clear()
+        os.environ.update(saved)
+
+
+def test_bench_rendezvous_under_torch_distributed_run():
+    """The driver's launch line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P):
+    the agent serves the store on MASTER_PORT, the ranks join it as clients."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "coord_check.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("SOLBENCH_STORE", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rank 0/2 ok" in r.stdout and "rank 1/2 ok" in r.stdout, (r.stdout + r.stderr)[-2000:]

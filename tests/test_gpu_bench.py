@@ -1,10 +1,10 @@
-"""bench.py end to end on the GPU box: the default single-GPU contract line, a two-rank rehearsal of the N>1 path started by
-bench.py itself (no launcher; all ranks on cuda:0, gloo gather through host copies - RCCL refuses two ranks on one device)
-whose assembled frame must equal the single-rank frame bit for bit, the same rehearsal under torch.distributed.run, and the
-RCCL communicator behind the C ABI exercised with the one rank a one-GPU box can hold."""
+"""bench.py end to end on the GPU box: the default single-GPU contract line; two- and three-rank rehearsals of the N>1 path started
+by bench.py itself (no launcher; all ranks on cuda:0, going through sol_comm_init / sol_gather over the test-only transport stub
+tests/stub_rccl - RCCL refuses two ranks on one device) whose assembled frame must equal the single-rank frame bit for bit; and the
+real RCCL communicator behind the C ABI exercised with the one rank a one-GPU box can hold. (The ranks' rendezvous under
+torch.distributed.run - the launcher's TCPStore - is covered on the CPU: tests/test_distributed_cpu.py.)"""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -41,30 +41,18 @@ def test_single_gpu_line_has_the_contract_fields():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "spp" in cb["sample"]
 
 
-@pytest.mark.parametrize("scaling,spp_total", [("strong", 16), ("weak", 32)])
-def test_two_rank_rehearsal_without_a_launcher(scaling, spp_total):
-    """`python bench.py --gpus 2` starts its own ranks; the assembled frame equals the single-rank frame."""
-    cmd = [sys.executable, "bench.py", "--gpus", "2", "--workload", "c1", "--spp", "16", "--steps", "1", "--warmup", "1", "--rehearse",
+@pytest.mark.parametrize("ranks,scaling,spp_total", [(2, "strong", 16), (2, "weak", 32), (3, "strong", 16)])
+def test_rehearsal_without_a_launcher_goes_through_sol_gather(ranks, scaling, spp_total):
+    """`python bench.py --gpus N --rehearse` starts its own ranks; the data path is the real one (sol_comm_init, sol_render, sol_gather
+    with world > 1) over the stub transport; the frame rank 0 assembles equals the single-rank frame."""
+    cmd = [sys.executable, "bench.py", "--gpus", str(ranks), "--workload", "c1", "--spp", "16", "--steps", "1", "--warmup", "1", "--rehearse",
            "--scaling", scaling, "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["spp_total"] == spp_total and d["rehearsal_frame_check"] is True
-
-
-def test_two_rank_rehearsal_under_torch_distributed_run():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "bench.py", "--gpus", "2", "--workload", "c1", "--spp", "16", "--steps", "1", "--warmup", "1",
-           "--rehearse", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and d["config"]["spp_total"] == 16 and d["rehearsal_frame_check"] is True
+    assert d["n_gpus"] == ranks and d["scaling"] == scaling and d["config"]["spp_total"] == spp_total
+    assert d["rehearsal_frame_check"] is True and d["rccl_ranks"] == ranks and "sol_gather" in d["config"]["sharding"]
 
 
 def test_a_supplied_obj_replaces_the_stand_in():
