@@ -64,6 +64,11 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
   uint32_t item_rays0 = 0;  // (counted builds) ray count when the lane took its item
   __shared__ uint32_t reservoir[SOL_WG / 64][2];  // per wave: next reserved item, end of the reservation
   if (lane == 0) { reservoir[tid >> 6][0] = 0u; reservoir[tid >> 6][1] = 0u; }
+#if SOL_COOP_TRIANGLES
+  __shared__ uint32_t coop_queue[SOL_WG / 64][64];  // per wave: the pending triangle tests of a cooperative primitive part (A/B build)
+#else
+  lds_u32* const coop_queue[SOL_WG / 64] = {};
+#endif
 
   for (;;) {
     // ---- lanes whose search is over: shade the vertex, then start the next ray of the path / sample / item ----
@@ -150,7 +155,11 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
       if (am == 0ull) break;
       const unsigned long long live = sol_ballot(true);
       if (am != live && (uint32_t)__popcll(am) * 64u < P.switch_below * (uint32_t)__popcll(live)) break;
+#if SOL_WAVE_STEP && !SOL_WORLD_BINARY
+      trav_step_wave<COUNT, MEDIUM>(S, t, act, st, (volatile lds_u32*)coop_queue[tid >> 6], p.rng, p.depth, cnt);
+#else
       if (act) trav_step<COUNT, MEDIUM, SOL_WORLD_BINARY>(S, t, st, p.rng, p.depth, cnt);
+#endif
     }
 #if SOL_LOOP_PRIO
     __builtin_amdgcn_s_setprio(0);

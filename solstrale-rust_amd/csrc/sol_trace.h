@@ -433,6 +433,61 @@ DEV void prim_test(const DevScene& S, Trav& t, const Stack& st, uint32_t kind, u
   }
 }
 
+// Part 1 of a step of a 7-wide search, for a lane without pending primitives: takes the nearest child of the lane's node group
+// (popping a group first when its own is used up), pushes the rest of the group, fetches that node (64 bytes) and tests its seven
+// child boxes: a new node group and a new primitive group.
+template <bool COUNT>
+DEV void wide_visit(Trav& t, const Stack& st, Counters& cnt) {
+  const uint32_t oct = t.oct;
+#if SOL_FETCH_PRIO
+  __builtin_amdgcn_s_setprio(SOL_FETCH_PRIO % 10);  // the wave about to fetch goes first: its memory latency starts now
+#endif
+  uint32_t g0 = t.g0, g1 = t.g1;
+  if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
+    stack_pop2(st, t.sp, g0, g1);
+  }
+  const uint32_t p = (uint32_t)__builtin_ctz(g0 >> 24);  // nearest: lowest bit in visit order
+  const uint32_t slot = p ^ oct;
+  g0 &= ~(1u << (24u + p));
+  const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(g1, 15u, slot));  // rank among the node's inner children: imask bits below `slot`
+  if ((g0 >> 24) != 0u) {  // siblings left: one stack entry for all of them
+    stack_push(st, t.sp, g0);
+    stack_push(st, t.sp, g1);
+    if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
+  }
+  const float4* wp = reinterpret_cast<const float4*>(st.wides + idx);
+  const float4 h = ldg_f4(wp);
+  const uint4 qa = ldg_u4(wp + 1), qb = ldg_u4(wp + 2), qc = ldg_u4(wp + 3);
+#if SOL_FETCH_PRIO
+  asm volatile("s_setprio %0" ::"n"(SOL_LOOP_PRIO) : "memory");  // (after the loads are issued; asm: the builtin may be moved across them)
+#endif
+  if (COUNT) cnt.node_visits++;
+#if defined(SOL_EXP_VMEM) || defined(SOL_EXP_VALU) || defined(SOL_EXP_LDS)
+  // Sensitivity probes (A/B builds only, tests/tools/variants.py): extra work per node visit that changes no result -
+  // SOL_EXP_VMEM more 16-byte loads of this node (L1 hits), SOL_EXP_VALU more vector instructions, SOL_EXP_LDS more LDS stores -
+  // to see which pipe the kernel's time follows.
+  {
+    uint32_t zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+#ifdef SOL_EXP_VMEM
+#pragma unroll
+    for (int k = 0; k < SOL_EXP_VMEM; ++k) { const uint4 x = ldg_u4(wp + zero + (k % 4)); asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
+#endif
+#ifdef SOL_EXP_VALU
+    float dummy = h.x;
+#pragma unroll
+    for (int k = 0; k < SOL_EXP_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy));
+    asm volatile("" ::"v"(dummy));
+#endif
+#ifdef SOL_EXP_LDS
+#pragma unroll
+    for (int k = 0; k < SOL_EXP_LDS; ++k) st.lds[(SOL_LDS_STACK - 1) * SOL_WG] = zero;  // (top level: scratch unless the stack is full)
+#endif
+  }
+#endif
+  wide_node_test<COUNT>(st, t, oct, h, qa, qb, qc);
+}
+
 // One step of a search. BINARY selects which tree this search walks: the 2-wide DNode tree (constant-medium boundaries,
 // whose search interval includes negative t) or the 7-wide DWide tree (the world).
 //   2-wide: visits the node or primitive t.cur, then moves to the next reference (near child, or popped from the stack).
@@ -444,7 +499,6 @@ template <bool COUNT, bool MEDIUM, bool BINARY>
 DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
   phase_tick<COUNT>(cnt, 0);
   if (!BINARY) {
-    const uint32_t oct = t.oct;
 #ifdef SOL_PROBE_STEP
     // probe build (tests/tools/variants.py, perf_quick --phases): [0] lanes in node parts, [1] 64 per node part executed by the
     // wave, [2] / [3] the same for primitive parts, [4] lanes holding primitives while a node part runs, [5] of those, the
@@ -458,55 +512,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
       }
     }
 #endif
-    if ((t.pg >> 24) == 0u) {
-#if SOL_FETCH_PRIO
-      __builtin_amdgcn_s_setprio(SOL_FETCH_PRIO % 10);  // the wave about to fetch goes first: its memory latency starts now
-#endif
-      uint32_t g0 = t.g0, g1 = t.g1;
-      if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
-        stack_pop2(st, t.sp, g0, g1);
-      }
-      const uint32_t p = (uint32_t)__builtin_ctz(g0 >> 24);  // nearest: lowest bit in visit order
-      const uint32_t slot = p ^ oct;
-      g0 &= ~(1u << (24u + p));
-      const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(g1, 15u, slot));  // rank among the node's inner children: imask bits below `slot`
-      if ((g0 >> 24) != 0u) {  // siblings left: one stack entry for all of them
-        stack_push(st, t.sp, g0);
-        stack_push(st, t.sp, g1);
-        if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
-      }
-      const float4* wp = reinterpret_cast<const float4*>(st.wides + idx);
-      const float4 h = ldg_f4(wp);
-      const uint4 qa = ldg_u4(wp + 1), qb = ldg_u4(wp + 2), qc = ldg_u4(wp + 3);
-#if SOL_FETCH_PRIO
-      asm volatile("s_setprio %0" ::"n"(SOL_LOOP_PRIO) : "memory");  // (after the loads are issued; asm: the builtin may be moved across them)
-#endif
-      if (COUNT) cnt.node_visits++;
-#if defined(SOL_EXP_VMEM) || defined(SOL_EXP_VALU) || defined(SOL_EXP_LDS)
-      // Sensitivity probes (A/B builds only, tests/tools/variants.py): extra work per node visit that changes no result -
-      // SOL_EXP_VMEM more 16-byte loads of this node (L1 hits), SOL_EXP_VALU more vector instructions, SOL_EXP_LDS more LDS stores -
-      // to see which pipe the kernel's time follows.
-      {
-        uint32_t zero;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-#ifdef SOL_EXP_VMEM
-#pragma unroll
-        for (int k = 0; k < SOL_EXP_VMEM; ++k) { const uint4 x = ldg_u4(wp + zero + (k % 4)); asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
-#endif
-#ifdef SOL_EXP_VALU
-        float dummy = h.x;
-#pragma unroll
-        for (int k = 0; k < SOL_EXP_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy));
-        asm volatile("" ::"v"(dummy));
-#endif
-#ifdef SOL_EXP_LDS
-#pragma unroll
-        for (int k = 0; k < SOL_EXP_LDS; ++k) st.lds[(SOL_LDS_STACK - 1) * SOL_WG] = zero;  // (top level: scratch unless the stack is full)
-#endif
-      }
-#endif
-      wide_node_test<COUNT>(st, t, oct, h, qa, qb, qc);
-    }
+    if ((t.pg >> 24) == 0u) wide_visit<COUNT>(t, st, cnt);
     // status for the callers' loops, and for the postponing rule below
     const bool has_prim = (t.pg >> 24) != 0u;
     const bool has_inner = !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);
@@ -599,6 +605,145 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
   if (cur == REF_DONE || kind == SOL_REF_NODE) { t.cur = cur; return; }
   prim_test<COUNT, MEDIUM>(S, t, st, kind, SOL_REF_INDEX(cur), rng, depth, cnt);
   t.cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
+}
+
+// One step of a 7-wide world search for a whole WAVE (every lane of the wave calls it; `act`: the lane has a running search) - the
+// product kernel's form of trav_step: the same two parts, but the votes on the step's shape (does any lane hold primitives? are
+// they postponed?) are taken by the whole wave once instead of inside the divergent region of the searching lanes
+// (MI355X, 64 spp, ms: C3 69.57 -> 68.85, C2 44.0 -> 43.45, C1 10.37 -> 10.30; profiles/r03_coop_triangles_ab.txt).
+//
+// -DSOL_COOP_TRIANGLES=1 (an A/B build; MEASURED SLOWER, kept as the record of the experiment): the primitive part COOPERATIVELY.
+// A lane with pending primitives tests one of them per step and the primitive part runs with a quarter of the wave's lanes
+// (C3: 16.0 of 64), a fifth of all vector instructions of a launch at that occupancy. In the cooperative form all
+// pending TRIANGLE tests of the wave - every hit leaf slot of every lane's primitive group - are dealt out over all 64 lanes,
+// finished and node-only lanes included: the owners list their tests in a 64-entry LDS queue (exclusive prefix of their counts by
+// three ballots), the r-th enabled lane takes entry r, gathers the owner's ray and best t (ds_bpermute: the LDS crossbar, no
+// memory), tests the triangle, and the owners collect the results by the (t, dfs) rule of `better` - a total order, so neither
+// who tests nor in which order changes the hit (frames bit-identical). It loses: listing and collecting are loops over the
+// largest primitive group of the wave (~12 + ~25 vector instructions per turn) around a 60-instruction test, and a primitive part
+// deals out 20 - 30 tests, not 64: C3 69.6 -> 74.1 ms with the postponing rule at 8 lanes, 72.0 at 16, 75.0 at 24, 80.5 at 4.
+template <bool COUNT, bool MEDIUM>
+DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, volatile lds_u32* queue, const Rng& rng, uint32_t depth,
+                        Counters& cnt) {
+  if (act) {
+    phase_tick<COUNT>(cnt, 0);
+    if ((t.pg >> 24) == 0u) wide_visit<COUNT>(t, st, cnt);
+  }
+  const bool has_prim = act && (t.pg >> 24) != 0u;
+  const bool has_inner = act && !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);
+  if (act && !has_prim && !has_inner) t.cur = REF_DONE;
+  const unsigned long long prim_m = sol_ballot(has_prim);
+  if (prim_m == 0ull) return;
+#if SOL_PRIM_MIN > 1
+  // Postponed primitive tests: while fewer than SOL_PRIM_MIN lanes hold primitives and some lane has an inner node to visit next
+  // turn, the holders wait (a later primitive part then has more tests to deal out)
+  if (sol_ballot(has_inner) != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) return;
+#endif
+  const uint32_t lkind = t.g1 >> 29;
+  if (has_prim && (SOL_COOP_TRIANGLES == 0 || lkind != SOL_LEAF_TRIANGLES)) {  // part 2 of trav_step: ONE of the lane's own primitives
+    const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
+    t.pg &= ~(1u << (24u + slot));
+    uint32_t idx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(t.g1, 22u, slot));  // lmask bits below `slot`
+    if (lkind == SOL_LEAF_TRIANGLES) {  // (straight to their test, not through prim_test's chain: nine vector instructions less)
+      triangle_prim_test<COUNT>(t, st, idx, cnt);
+    } else {
+      uint32_t kind = lkind == SOL_LEAF_SPHERES ? SOL_REF_SPHERE : SOL_REF_QUAD;
+      if (lkind == SOL_LEAF_REFS) {  // mixed node: the reference is listed
+        const uint32_t r = ldg_u32(S.leaf_refs + idx);
+        kind = SOL_REF_KIND(r);
+        idx = SOL_REF_INDEX(r);
+      }
+      prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
+    }
+    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
+  }
+#if SOL_COOP_TRIANGLES
+  const bool tri_owner = has_prim && lkind == SOL_LEAF_TRIANGLES;
+  if (sol_ballot(tri_owner) == 0ull) return;
+  // ---- the wave's pending triangle tests, dealt out over all its lanes ----
+  const uint32_t lane = __lane_id();
+  const uint32_t pend = tri_owner ? (t.pg >> 24) : 0u;
+  const uint32_t n = (uint32_t)__popc(pend);
+  const unsigned long long m0 = sol_ballot((n & 1u) != 0u), m1 = sol_ballot((n & 2u) != 0u), m2 = sol_ballot((n & 4u) != 0u);
+  const uint32_t first = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u)) +
+                         2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)) +
+                         4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+  const uint32_t total = (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1) + 4u * (uint32_t)__popcll(m2);
+  // Entry r of the queue goes to the r-th ENABLED lane of the wave (at the end of a launch lanes without work have left the kernel:
+  // nothing may be dealt to them, and a bpermute reads registers of enabled lanes only)
+  const unsigned long long live = sol_ballot(true);
+  const uint32_t n_live = (uint32_t)__popcll(live);
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+  // owners list their tests (triangle index | owner lane << 24) at queue[first ..]; what does not fit stays pending
+  uint32_t listed = 0u;  // the slots this lane got into the queue
+  {
+    uint32_t rest = pend, pos = first;
+    while (rest != 0u && pos < n_live) {
+      const uint32_t slot = (uint32_t)__builtin_ctz(rest);
+      rest &= rest - 1u;
+      listed |= 1u << slot;
+      queue[pos++] = ((t.pg & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(t.g1, 22u, slot))) | (lane << 24);
+    }
+  }
+  const uint32_t n_tests = min(total, n_live);
+  const bool tester = rank < n_tests;
+  const uint32_t e = tester ? queue[rank] : (lane << 24);
+  if (tester) queue[rank] = lane;  // (its own entry, read above: where the owner finds the result)
+  const uint32_t owner4 = (e >> 24) << 2;  // byte address of the owner lane for ds_bpermute (all lanes execute the gathers: a
+                                           // bpermute reads registers of ENABLED lanes only)
+  f3 o, d;
+  o.x = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.o.x)));
+  o.y = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.o.y)));
+  o.z = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.o.z)));
+  d.x = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.d.x)));
+  d.y = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.d.y)));
+  d.z = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.d.z)));
+  const float tmax = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.h.t)));
+  float rt = __builtin_huge_valf(), ru = 0.0f, rv = 0.0f;  // this lane's result: t = +inf when the triangle is not hit
+  uint32_t rdfs = 0u;
+  const uint32_t ridx = e & SOL_WIDE_MAX_INDEX;
+  if (tester) {
+    const float4* tp = reinterpret_cast<const float4*>(st.tris + ridx);
+#if SOL_FETCH_PRIO >= 10
+    __builtin_amdgcn_s_setprio(SOL_FETCH_PRIO / 10);
+#endif
+    const float4 p0 = ldg_f4(tp), p1 = ldg_f4(tp + 1), p2 = ldg_f4(tp + 2);
+#if SOL_FETCH_PRIO >= 10
+    asm volatile("s_setprio %0" ::"n"(SOL_LOOP_PRIO) : "memory");
+#endif
+    DTri T;
+    T.v0x = p0.x; T.v0y = p0.y; T.v0z = p0.z; T.e1x = p0.w; T.e1y = p1.x; T.e1z = p1.y; T.e2x = p1.z; T.e2y = p1.w; T.e2z = p2.x;
+    rdfs = __float_as_uint(p2.y);
+    if (COUNT) cnt.triangle_tests++;
+    float tt, u, v;
+    if (tri_test(T, o, d, RAY_MIN_F, tmax, tt, u, v)) { rt = tt; ru = u; rv = v; }  // (a world search starts at RAY_MIN_F: trav_begin)
+  }
+  // owners collect their results, in queue order. The loop's trip count is wave-uniform and every lane executes the gathers.
+  {
+    uint32_t rest = listed, pos = first;
+    while (sol_ballot(rest != 0u) != 0ull) {
+      const uint32_t src4 = (rest != 0u ? queue[pos] : lane) << 2;
+      const float tt = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)src4, (int)__float_as_uint(rt)));
+      const float u = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)src4, (int)__float_as_uint(ru)));
+      const float v = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)src4, (int)__float_as_uint(rv)));
+      const uint32_t dfs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)rdfs);
+      const uint32_t idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)ridx);
+      if (rest != 0u) {
+        rest &= rest - 1u;
+        pos++;
+        if (tt < __builtin_huge_valf() && better(tt, dfs, t.h)) {
+          t.h.t = tt; t.h.ref = SOL_MAKE_REF(SOL_REF_TRIANGLE, idx); t.h.dfs = dfs; t.h.u = u; t.h.v = v;
+        }
+      }
+    }
+  }
+  if (tri_owner) {
+    t.pg &= ~(listed << 24);
+    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
+  }
+#else
+  (void)queue;
+#endif
 }
 
 // Run-to-completion form.

@@ -36,6 +36,13 @@
 #ifndef SOL_LEAF_KIND_DISPATCH
 #define SOL_LEAF_KIND_DISPATCH 1  // primitive part of trav_step: 0 every kind through prim_test's chain, 1 triangle leaves direct
 #endif
+#ifndef SOL_WAVE_STEP
+#define SOL_WAVE_STEP 1           // search loop of the product kernel: 1 = trav_step_wave (the whole wave votes on the shape of a step), 0 =
+                                  // trav_step under the mask of the searching lanes (round 2)
+#endif
+#ifndef SOL_COOP_TRIANGLES
+#define SOL_COOP_TRIANGLES 0      // 1: A/B build - the wave's pending triangle tests dealt out over all its lanes (trav_step_wave; measured slower)
+#endif
 #define SOL_CHUNK 16        // samples per work item; fixed so that summation order never depends on the partition
 #define SOL_TILE 8          // 8x8-pixel blocks = one wave's worth of adjacent work items
 #define SOL_POOL_MAX 1024   // path slots per wave in the pool kernel (u16 queue entries: 2 KiB of LDS per wave)
