@@ -64,6 +64,9 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
   uint32_t item_rays0 = 0;  // (counted builds) ray count when the lane took its item
   __shared__ uint32_t reservoir[SOL_WG / 64][2];  // per wave: next reserved item, end of the reservation
   if (lane == 0) { reservoir[tid >> 6][0] = 0u; reservoir[tid >> 6][1] = 0u; }
+#if SOL_PARK_PATH
+  __shared__ float park[6][SOL_WG];
+#endif
 #if SOL_COOP_TRIANGLES
   __shared__ uint32_t coop_queue[SOL_WG / 64][64];  // per wave: the pending triangle tests of a cooperative primitive part (A/B build)
 #else
@@ -77,6 +80,10 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         in_flight = false;
         if (COUNT) cnt.rays++;
         p.o = t.o; p.d = t.d;  // (the ray lives in the search state while it is traced)
+#if SOL_PARK_PATH
+        p.A = mk3(park[0][tid], park[1][tid], park[2][tid]);
+        p.C = mk3(park[3][tid], park[4][tid], park[5][tid]);
+#endif
         f3 c;
         if (shade_vertex<COUNT>(S, p, t.h, c, cnt)) {
           sum = sum + c;  // add_row_data (src/renderer/mod.rs:361-365): sums, not means
@@ -140,6 +147,11 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         generate_path<COUNT>(S, P.seed_lo, P.seed_hi, it.px, it.py, s, p, cnt);
         alive = true;
       }
+#if SOL_PARK_PATH
+      // The path's throughput (A, C: six registers) is dead during the search: parked in LDS until the next shading, so that the
+      // search loop's live set stays below the point where edits of this block perturb its register allocation
+      park[0][tid] = p.A.x; park[1][tid] = p.A.y; park[2][tid] = p.A.z; park[3][tid] = p.C.x; park[4][tid] = p.C.y; park[5][tid] = p.C.z;
+#endif
       // world.hit(ray, RAY_INTERVAL) (src/renderer/mod.rs:165)
       trav_begin<!SOL_WORLD_BINARY>(t, p.o, p.d, RAY_MIN_F, inf, SOL_WORLD_ROOT(S), S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
       in_flight = true;

@@ -251,6 +251,9 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
               __builtin_signbitf(t.inv.z), te))
       t.cur = REF_DONE;
   }
+  // A 7-wide search evaluates its slabs in t-space with the inverse direction clamped to +-1e30 (wide_node_test: an exactly zero
+  // direction component becomes the containment test it should be instead of NaN); clamped here, once per ray, not once per node
+  if (WIDE) t.inv = mk3(__builtin_amdgcn_fmed3f(t.inv.x, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(t.inv.y, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(t.inv.z, -1e30f, 1e30f));
 }
 
 template <bool COUNT>
@@ -269,7 +272,33 @@ DEV float sol_min_raw(float a, float b) {
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-#if SOL_HALF_PLANES
+#if SOL_CLAMP_SLABS
+// The slab parameters are evaluated in units of the cull distance, t' = t / min(best t, 1e30): the search interval is then [0, 1]
+// and the CLAMP output modifier of the plane FMAs does what a maximum with 0 (near planes) and a minimum with the cull distance
+// (far planes) did - two of the twelve vector instructions per child. A child must be visited iff te' < tx', STRICTLY: a box wholly
+// beyond the cull distance clamps to te' = tx' = 1, one wholly behind the origin to 0 = 0. (A box holding a primitive that a ray
+// really hits has te < tx by the builder's margin of three pads, 2.7 times the rounding error of this evaluation - sol_tree.h -, so
+// the strict comparison loses nothing; the scale is taken a millionth short of 1 / cull so that a tie at t = cull stays inside.)
+// NaN (an overflowing plane product) clamps to 0 under DX10_CLAMP: no constraint for a near plane; planes do not overflow for
+// |inv| <= 1e30 / t_min and node scales below 1e5.
+#define SOL_FMA_MIX_LO(d, h2, b, a) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0] clamp" : "=v"(d) : "v"(h2), "v"(b), "v"(a))
+#define SOL_FMA_MIX_HI(d, h2, b, a) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(d) : "v"(h2), "v"(b), "v"(a))
+#define SOL_FMA_MIX_x SOL_FMA_MIX_LO
+#define SOL_FMA_MIX_y SOL_FMA_MIX_HI
+typedef uint32_t sol_h2;  // two halves (1024 + q0, 1024 + q1): v_perm_b32 puts two plane bytes under the fp16 exponent of 1024
+#define SOL_H2(w, sel) __builtin_amdgcn_perm(0x64646464u, (w), (sel))
+#define SOL_WIDE_CHILD(i, hnx, hny, hnz, hfx, hfy, hfz, e)                                                             \
+  {                                                                                                                     \
+    float tnx, tfx, tny, tfy, tnz, tfz;                                                                                 \
+    SOL_FMA_MIX_##e(tnx, hnx, bx, ax); SOL_FMA_MIX_##e(tfx, hfx, bx, ax);                                               \
+    SOL_FMA_MIX_##e(tny, hny, by, ay); SOL_FMA_MIX_##e(tfy, hfy, by, ay);                                               \
+    SOL_FMA_MIX_##e(tnz, hnz, bz, az); SOL_FMA_MIX_##e(tfz, hfz, bz, az);                                               \
+    float te, tx;                                                                                                        \
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(te) : "v"(tnx), "v"(tny), "v"(tnz));                                         \
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tx) : "v"(tfx), "v"(tfy), "v"(tfz));                                         \
+    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(te - tx), 31u); /* (here: the HIT bits: sign of te - tx) */   \
+  }
+#elif SOL_HALF_PLANES
 // Plane bytes become floats two at a time: v_perm_b32 puts two bytes of a plane word under the fp16 exponent of 1024 - the halves
 // (1024 + q0, 1024 + q1), exact - and v_fma_mix_f32 takes a half as its first factor: t = (1024 + q) * B + (A - 1024 * B). 24 + 42
 // vector instructions per node instead of 42 conversions + 42 FMAs, and the kernel's time follows its vector instruction count
@@ -319,8 +348,14 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
   // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
   // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
-  const float ivx = __builtin_amdgcn_fmed3f(t.inv.x, -1e30f, 1e30f), ivy = __builtin_amdgcn_fmed3f(t.inv.y, -1e30f, 1e30f);
-  const float ivz = __builtin_amdgcn_fmed3f(t.inv.z, -1e30f, 1e30f);
+#if SOL_CLAMP_SLABS
+  // (units of the cull distance, a millionth short: see SOL_WIDE_CHILD; best t is a positive float or +inf, never NaN)
+  const float rc = __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(t.h.t, RAY_MIN_F, 1e30f) * 1.000001f);
+  (void)cull_t;
+  const float ivx = t.inv.x * rc, ivy = t.inv.y * rc, ivz = t.inv.z * rc;  // (t.inv: clamped to +-1e30 by trav_begin)
+#else
+  const float ivx = t.inv.x, ivy = t.inv.y, ivz = t.inv.z;
+#endif
   const float ax = (h.x - t.o.x) * ivx, bx = scx * ivx;
   const float ay = (h.y - t.o.y) * ivy, by = scy * ivy;
   const float az = (h.z - t.o.z) * ivz, bz = scz * ivz;
@@ -329,7 +364,7 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   const uint32_t nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
   const uint32_t ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
   const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
-#if SOL_HALF_PLANES
+#if SOL_HALF_PLANES || SOL_CLAMP_SLABS
   {
     const float ax0 = ax, ay0 = ay, az0 = az;
     const float ax = fmaf(-1024.0f, bx, ax0), ay = fmaf(-1024.0f, by, ay0), az = fmaf(-1024.0f, bz, az0);  // (shadow the plain addends)
@@ -356,7 +391,11 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 0)
   SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
 #endif
+#if SOL_CLAMP_SLABS
+  const uint32_t hits = miss;  // (the clamped form shifts in HIT bits)
+#else
   const uint32_t hits = ~miss;
+#endif
   const uint32_t imask = (meta >> 15) & 0x7Fu, lmask = (meta >> 22) & 0x7Fu;
   // inner hits into visit order: bit p <- bit p ^ octant (three conditional butterfly stages)
   uint32_t ih = hits & imask;

@@ -20,6 +20,9 @@
                             // MI355X, 1080p x 128 spp, C3 / C2 ms: 1: 199.8 / 128.4, 4: 196.6 / 126.5, 8: 193.1 / 122.5,
                             // 12: 193.0 / 122.6, 16: 199.1 / 129.7, 24: 215.7 / 148.0
 #endif
+#ifndef SOL_CLAMP_SLABS
+#define SOL_CLAMP_SLABS 1         // node test in units of the cull distance with clamped plane FMAs (sol_trace.h); implies the half-plane form
+#endif
 #ifndef SOL_HALF_PLANES
 #define SOL_HALF_PLANES 1
 #endif
@@ -39,6 +42,9 @@
 #ifndef SOL_WAVE_STEP
 #define SOL_WAVE_STEP 1           // search loop of the product kernel: 1 = trav_step_wave (the whole wave votes on the shape of a step), 0 =
                                   // trav_step under the mask of the searching lanes (round 2)
+#endif
+#ifndef SOL_PARK_PATH
+#define SOL_PARK_PATH 0           // product kernel: the path's throughput registers (A, C) live in LDS during a search (sol_render.hip)
 #endif
 #ifndef SOL_COOP_TRIANGLES
 #define SOL_COOP_TRIANGLES 0      // 1: A/B build - the wave's pending triangle tests dealt out over all its lanes (trav_step_wave; measured slower)
