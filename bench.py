@@ -74,7 +74,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c4", "c5", "profiling"],
+                    help="c1..c5: the BASELINE.json configs (default c3, the one the metric is quoted on); profiling: the one workload the reference "
+                         "itself defines (src/bin/profiling.rs:14-37: its test scene, 800x400, 1000 spp)")
+    ap.add_argument("--camera-preset", default="default", choices=["default", "interior", "closeup"],
+                    help="STRESS variants of the stand-ins, reported beside the headline, never instead of it: c3/c4 'interior' (under the gallery, "
+                         "looking along the colonnade: every camera ray hits), c5 'closeup' (the statue fills the frame, glass in front of metal)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = the workload's total spp split by tiles over the ranks (default); weak = that spp per GPU")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel of the job (strong) / per GPU (weak); default: the workload's")
@@ -282,6 +287,8 @@ def pmc_passes(args, spp):
                                               "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-build"]
             if args.hdri:
                 cmd += ["--hdri"]
+            if args.camera_preset != "default":
+                cmd += ["--camera-preset", args.camera_preset]
             if args.obj:
                 cmd += ["--obj", args.obj] + (["--camera", args.camera] if args.camera else []) + (["--light", args.light] if args.light else [])
             try:
@@ -311,7 +318,10 @@ def make_scene(args, spp_total):
     from solstrale_amd import RenderConfig, scenes
     wl = args.workload
     w, h, spp0 = {"c1": (400, 400, 50), "c2": (1920, 1080, 256), "c3": (1920, 1080, 512), "c4": (3840, 2160, 1024),
-                  "c5": (1920, 1080, 2048)}[wl]
+                  "c5": (1920, 1080, 2048), "profiling": (800, 400, 1000)}[wl]
+    preset = args.camera_preset
+    if preset != "default" and not ((wl in ("c3", "c4") and preset == "interior") or (wl == "c5" and preset == "closeup")) or (preset != "default" and args.obj):
+        raise SystemExit(f"--camera-preset {preset} does not exist for workload {wl}")
     if args.obj:
         cam = light = None
         if args.camera:
@@ -324,12 +334,18 @@ def make_scene(args, spp_total):
         name = f"{wl.upper()} shape ({w}x{h}) on the supplied OBJ file {os.path.basename(args.obj)} (host OBJ+MTL loader), 1 quad light + sky"
     elif wl in ("c3", "c4"):
         name = (f"{wl.upper()} Sponza-class procedural atrium (stand-in: the real sponza.obj is not available offline; --obj takes one), "
-                f"{scenes.SPONZA_TRIANGLES} triangles, 24 Lambertian materials (8 image-textured), 1 quad light + sky")
-        make = lambda rc: scenes.sponza_like(rc)
+                f"{scenes.SPONZA_TRIANGLES} triangles, 24 Lambertian materials (8 image-textured), 1 quad light + sky" +
+                (" - STRESS camera 'interior' (under the gallery along the colonnade; not the headline view)" if preset == "interior" else ""))
+        make = lambda rc: scenes.sponza_like(rc, camera=preset)
     elif wl == "c5":
         name = (f"C5 statue-class displaced mesh (stand-in), ~{scenes.STATUE_TRIANGLES} triangles, Metal(0.1) + Dielectric(1.5), 1 quad light" +
-                (" + procedural 2048x1024 HDR environment map (EXTENSION: not in the reference)" if args.hdri else ""))
-        make = lambda rc: scenes.statue_like(rc, environment=args.hdri)
+                (" + procedural 2048x1024 HDR environment map (EXTENSION: not in the reference)" if args.hdri else "") +
+                (" - STRESS camera 'closeup' (the statue fills the frame, seen from above; not the default view)" if preset == "closeup" else ""))
+        make = lambda rc: scenes.statue_like(rc, environment=args.hdri, camera=preset)
+    elif wl == "profiling":
+        name = ("the reference's own profiling workload (src/bin/profiling.rs:14-37): create_test_scene (tests/scenes.rs:17-122: image texture, glass, "
+                "ConstantMedium, nested BVH, sphere + quad + triangle lights, aperture 0.1), 800x400, 1000 spp")
+        make = lambda rc: scenes.create_test_scene(rc)
     elif wl == "c2":
         name = "C2 Cornell box + 10000 Lambertian spheres"
         make = lambda rc: scenes.cornell_spheres(rc)
@@ -439,6 +455,7 @@ def worker(args):
     bytes_per_sample = algorithmic_bytes(st, sizes) / st["samples"]
     rays_per_sample = st["rays"] / st["samples"]
     launch_samples = st["samples"] // c_spp * last_call_spp  # samples of the launch k_ms belongs to (this rank)
+    pst = ds.path_stats()
 
     out = None
     if rank == 0:
@@ -458,6 +475,8 @@ def worker(args):
                                                            if world > 1 else "(single rank: un-permute only)")},
             "mrays_per_s": round(value * rays_per_sample, 2),
             "rays_per_sample": round(rays_per_sample, 4),
+            "primary_hit_fraction": round(pst["primary_hit_fraction"], 4),
+            "rays_per_path_histogram": {k: round(v, 4) for k, v in pst["rays_per_path_histogram"].items()},
             "rays_per_sample_note": "the open-roofed atrium ends most paths on the sky after ~3 rays; a closed interior costs several "
                                     "times more rays per sample - Mrays/s is the figure that transfers between scenes",
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -342,6 +342,16 @@ int sol_bloom_rgb8(SolScene* scene, const void* image_dev, uint32_t num_samples,
 int sol_gaussian_blur_weights(uint32_t kernel_size, double std_dev, double* out);
 
 int sol_stats(const SolScene* scene, SolStats* out);
+/* What the paths of the last instrumented render (sol_render_counted, one-path-per-lane kernel) looked like - how hard a workload
+ * is: the share of camera rays that hit something and the samples by the number of rays of their path (a path of n rays was
+ * scattered n - 1 times: src/renderer/shader.rs:62-125). No reference analogue. */
+typedef struct SolPathStats {
+  uint32_t size, pad;      /* in: sizeof(SolPathStats)                                                              */
+  uint64_t samples;
+  uint64_t primary_hits;   /* samples whose camera ray hit a primitive                                              */
+  uint64_t path_len[6];    /* samples with 1, 2, 3-4, 5-8, 9-16, 17 or more rays                                    */
+} SolPathStats;
+int sol_path_stats(const SolScene* scene, SolPathStats* out);
 
 /* Diagnostic, host only (no device needed): builds the 7-wide quantised tree of the world exactly as sol_scene_create does
  * (use_sah = 0: collapsed from the reference's topology, 1: from the 16-bin SAH rebuild, n > 1: from the n-bin rebuild; -1: the tree

@@ -172,6 +172,14 @@ int sol_scene_info(const SolScene* s, SolSceneInfo* out) {
   return SOL_OK;
 }
 
+int sol_path_stats(const SolScene* s, SolPathStats* out) {
+  if (!s || !out || out->size < 8 || out->size > 4096) return sol_fail(SOL_EINVAL, "bad argument (SolPathStats.size?)");
+  SolPathStats r = s->path_stats;
+  r.size = (uint32_t)std::min<size_t>(out->size, sizeof r);
+  std::memcpy(out, &r, r.size);
+  return SOL_OK;
+}
+
 int sol_scene_set_option(SolScene* s, int option, int64_t value) {
   if (!s) return sol_fail(SOL_EINVAL, "null scene");
   switch (option) {

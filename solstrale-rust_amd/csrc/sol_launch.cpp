@@ -195,6 +195,9 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
     s->stats.sphere_tests = c.sphere_tests; s->stats.quad_tests = c.quad_tests; s->stats.triangle_tests = c.triangle_tests;
     s->stats.shades = c.shades; s->stats.texel_fetches = c.texel_fetches; s->stats.max_stack = c.max_stack;
     for (int k = 0; k < 6; ++k) s->stats.phase[k] = c.phase[k];
+    s->path_stats.size = sizeof(SolPathStats);
+    s->path_stats.samples = c.samples; s->path_stats.primary_hits = c.primary_hits;
+    for (int k = 0; k < 6; ++k) s->path_stats.path_len[k] = c.path_len[k];
   }
   return SOL_OK;
 }

@@ -202,4 +202,10 @@ DEV void flush_counters(const Counters& cnt, DevCounters* __restrict__ dcnt) {
   atomicAdd(&dcnt->texel_fetches, (unsigned long long)cnt.texel_fetches);
   atomicMax(&dcnt->max_stack, (unsigned long long)cnt.max_stack);
   for (int k = 0; k < 6; ++k) atomicAdd(&dcnt->phase[k], (unsigned long long)cnt.phase[k]);
+  atomicAdd(&dcnt->primary_hits, (unsigned long long)cnt.primary_hits);
+  for (int k = 0; k < 6; ++k) atomicAdd(&dcnt->path_len[k], (unsigned long long)cnt.path_len[k]);
+}
+// (counted builds) a sample ended after `rays` rays: its bin in the path-length histogram
+DEV void count_path(Counters& cnt, uint32_t rays) {
+  cnt.path_len[rays <= 1u ? 0 : rays == 2u ? 1 : rays <= 4u ? 2 : rays <= 8u ? 3 : rays <= 16u ? 4 : 5]++;
 }

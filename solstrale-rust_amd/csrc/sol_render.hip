@@ -85,7 +85,9 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         p.C = mk3(park[3][tid], park[4][tid], park[5][tid]);
 #endif
         f3 c;
+        if (COUNT && p.depth == 0u && SOL_REF_KIND(t.h.ref) != SOL_REF_NONE) cnt.primary_hits++;
         if (shade_vertex<COUNT>(S, p, t.h, c, cnt)) {
+          if (COUNT) count_path(cnt, p.depth + 1u);  // (depth counts the scatterings before this vertex)
           sum = sum + c;  // add_row_data (src/renderer/mod.rs:361-365): sums, not means
           alive = false;
           s++;

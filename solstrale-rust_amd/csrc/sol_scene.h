@@ -99,6 +99,7 @@ struct SolScene {
   uint32_t* work = nullptr; uint32_t* spill = nullptr; size_t spill_words = 0;
   DevCounters* counters = nullptr;
   SolStats stats{};
+  SolPathStats path_stats{};
   bool has_medium = false;
   uint32_t tree_depth = 0;
   int rank = 0, world = 1;

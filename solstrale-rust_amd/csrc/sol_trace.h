@@ -31,6 +31,8 @@ struct Hit {
 struct Counters {
   uint32_t samples, rays, node_visits, sphere_tests, quad_tests, triangle_tests, shades, texel_fetches, max_stack;
   uint32_t phase[6];  // lane-utilisation instrumentation: (active lanes, 64 per executing wave) for traverse / shade / generate
+  uint32_t primary_hits;  // samples whose camera ray hit something
+  uint32_t path_len[6];   // samples by the number of rays of their path: 1, 2, 3-4, 5-8, 9-16, 17 and more
 };
 
 // Lane-utilisation instrumentation (COUNT builds only): every active lane counts itself, the first active lane of the

@@ -238,4 +238,5 @@ struct RenderParams {
 struct DevCounters {
   unsigned long long samples, rays, node_visits, sphere_tests, quad_tests, triangle_tests, shades, texel_fetches, max_stack;
   unsigned long long phase[6];
+  unsigned long long primary_hits, path_len[6];
 };

@@ -140,6 +140,10 @@ class SolSceneInfo(C.Structure):
                 ("tree_fallback", C.c_uint32), ("tree_name", C.c_char * 32), ("tree_note", C.c_char * 192)]
 
 
+class SolPathStats(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("pad", C.c_uint32), ("samples", C.c_uint64), ("primary_hits", C.c_uint64), ("path_len", C.c_uint64 * 6)]
+
+
 class SolTreeCheck(C.Structure):
     _fields_ = [("n_wide", C.c_uint32), ("n_leaf_refs", C.c_uint32), ("n_primitives", C.c_uint32), ("depth", C.c_uint32),
                 ("max_children", C.c_uint32), ("box_violations", C.c_uint32), ("leaf_mismatches", C.c_uint32),
@@ -191,6 +195,7 @@ def load_hip():
     _sig(lib, "sol_scene_build_times", C.c_int, [P, C.POINTER(C.c_double)])
     _sig(lib, "sol_scene_set_option", C.c_int, [P, C.c_int, C.c_int64])
     _sig(lib, "sol_scene_info", C.c_int, [P, C.POINTER(SolSceneInfo)])
+    _sig(lib, "sol_path_stats", C.c_int, [P, C.POINTER(SolPathStats)])
     _sig(lib, "sol_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)])
     _sig(lib, "sol_comm_init", C.c_int, [P, C.c_int, C.c_int, C.POINTER(C.c_uint8)])
     _sig(lib, "sol_comm_destroy", C.c_int, [P])
@@ -207,7 +212,7 @@ HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol
                "sol_render", "sol_render_counted", "sol_sync", "sol_read", "sol_unpermute", "sol_tonemap_rgb8",
                "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms",
                "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check", "sol_render_aux", "sol_clear_aux", "sol_read_aux",
-               "sol_scene_create_ex", "sol_scene_build_times", "sol_scene_set_option", "sol_scene_info", "sol_comm_unique_id", "sol_comm_init",
+               "sol_scene_create_ex", "sol_scene_build_times", "sol_scene_set_option", "sol_scene_info", "sol_path_stats", "sol_comm_unique_id", "sol_comm_init",
                "sol_comm_destroy", "sol_gather", "sol_comm_self_check", "sol_read_image", "sol_max_samples_per_call"]
 
 

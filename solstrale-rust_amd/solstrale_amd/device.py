@@ -114,6 +114,16 @@ class DeviceScene:
         return {"stack_bound": int(r.stack_bound), "lds_stack": int(r.lds_stack), "spill_stack": int(r.spill_stack),
                 "tree_fallback": bool(r.tree_fallback), "tree_name": r.tree_name.decode(), "tree_note": r.tree_note.decode()}
 
+    def path_stats(self):
+        """sol_path_stats of the last counted render: primary hit fraction and the path-length histogram (shares of the samples)."""
+        r = _abi.SolPathStats()
+        r.size = C.sizeof(r)
+        self._chk(self.lib.sol_path_stats(self.h, C.byref(r)))
+        n = max(1, int(r.samples))
+        bins = ("1", "2", "3-4", "5-8", "9-16", "17+")
+        return {"samples": int(r.samples), "primary_hit_fraction": int(r.primary_hits) / n,
+                "rays_per_path_histogram": {b: int(r.path_len[k]) / n for k, b in enumerate(bins)}}
+
     def max_samples_per_call(self):
         return int(self.lib.sol_max_samples_per_call(self.h))
 

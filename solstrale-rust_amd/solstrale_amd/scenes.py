@@ -127,10 +127,13 @@ def _procedural_texture(kind, size, seed):
 SPONZA_TRIANGLES = 262267
 
 
-def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1024, n_materials=24):
+def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1024, n_materials=24, camera="default"):
     """C3 stand-in: an atrium (floor, two-storey walls, galleries, 2x10x2 columns with arches, hanging drapes, partial
     roof) tessellated to exactly `n_triangles` Lambertian triangles, `n_materials` materials of which 8 carry image
-    textures, one Quad light above the roof opening and a constant sky background."""
+    textures, one Quad light above the roof opening and a constant sky background.
+    camera: "default" looks across the atrium with the roof opening and the sky in view (paths end early: ~3 rays per sample);
+    "interior" stands under the -z gallery and looks along the colonnade - floor, wall, gallery floor overhead and the columns fill
+    the frame, every camera ray hits, light arrives by bounces through the arches (the STRESS variant of the same geometry)."""
     rc = render_config or RenderConfig(width=1920, height=1080, samples_per_pixel=512)
     b = SceneBuilder()
     mats = []
@@ -219,8 +222,13 @@ def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1
     model = b.Bvh_range(first, n)  # like Obj::load -> Bvh::new(triangles) (src/loader/obj.rs:135)
     light = b.Quad((-6., Hh + 1.5, -2.0), (12., 0, 0), (0, 0, 4.0), b.DiffuseLight(18., 17., 15.))
     world = b.Bvh([model, light])
-    cam = CameraConfig(vertical_fov_degrees=55., aperture_size=0., look_from=(-13.0, 2.2, 0.6), look_at=(6.0, 4.5, -0.4),
-                       up=(0, 1, 0))
+    if camera == "interior":
+        cam = CameraConfig(vertical_fov_degrees=60., aperture_size=0., look_from=(-14.2, 1.7, -5.0), look_at=(13.0, 2.3, -4.9), up=(0, 1, 0))
+    elif camera == "default":
+        cam = CameraConfig(vertical_fov_degrees=55., aperture_size=0., look_from=(-13.0, 2.2, 0.6), look_at=(6.0, 4.5, -0.4),
+                           up=(0, 1, 0))
+    else:
+        raise ValueError(f"unknown camera preset {camera!r}")
     return b.finish(world, cam, (0.35, 0.5, 0.75), rc)
 
 
@@ -300,7 +308,7 @@ def procedural_sky(width=2048, height=1024, sun_dir=(0.45, 0.7, -0.55), sun_radi
 STATUE_TRIANGLES = 1_090_000
 
 
-def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES, environment=False):
+def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES, environment=False, camera="default"):
     """C5 stand-in: a procedurally displaced "statue" of about 1.09 M triangles - a noise-displaced body of
     Metal(fuzz 0.1), a Dielectric(1.5) head and a glass orb, a Lambertian plinth and drapery - on a floor quad under one
     quad light, constant background. (The Happy Buddha mesh and an HDRI light are not available / not in the reference.)"""
@@ -351,7 +359,12 @@ def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES, environment=Fa
     orb = b.Sphere((2.2, 0.7, 1.2), 0.7, glass)
     floor = b.Quad((-12., 0., -12.), (24., 0, 0), (0, 0, 24.), b.Lambertian(b.SolidColor(.4, .42, .45)))
     light = b.Quad((-2.5, 8.5, -1.0), (5., 0, 0), (0, 0, 4.), b.DiffuseLight(20., 19., 17.))
-    cam = CameraConfig(vertical_fov_degrees=38., aperture_size=0., look_from=(4.5, 3.6, 8.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
+    if camera == "closeup":  # STRESS variant: the statue fills the frame, seen from above so that the glass head lies in front of the metal body
+        cam = CameraConfig(vertical_fov_degrees=40., aperture_size=0., look_from=(1.6, 7.2, 3.4), look_at=(0.0, 3.1, 0.0), up=(0, 1, 0))
+    elif camera == "default":
+        cam = CameraConfig(vertical_fov_degrees=38., aperture_size=0., look_from=(4.5, 3.6, 8.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
+    else:
+        raise ValueError(f"unknown camera preset {camera!r}")
     if environment:  # EXTENSION (not in the reference): the "HDRI env light" of BASELINE.json's config 5, as a procedural HDR sky
         b.environment(procedural_sky(), 1.0)
     return b.finish(b.Bvh([model, orb, floor, light]), cam, (0.25, 0.3, 0.4), rc)

@@ -189,6 +189,29 @@ def test_c5_statue_class_crop():
     assert_parity(sc, 8, rect=(900, 60, 1028, 188))     # glass head (x 830-1020, y 55-255) against the background
 
 
+def test_stress_cameras_and_the_profiling_workload():
+    """The stress variants bench.py reports beside the headline (--camera-preset interior / closeup) and the reference's own profiling
+    workload (src/bin/profiling.rs:14-37: create_test_scene at 800x400): one 128x128 crop each against the oracle, and the path
+    statistics the bench line carries (sol_path_stats) - every camera ray of the interior view hits, its paths are longer."""
+    inner = scenes.sponza_like(RenderConfig(1920, 1080, 8), camera="interior")
+    assert_parity(inner, 8, rect=(896, 476, 1024, 604))
+    assert_parity(scenes.statue_like(RenderConfig(1920, 1080, 8), camera="closeup"), 8, rect=(896, 476, 1024, 604))
+    assert_parity(scenes.create_test_scene(RenderConfig(800, 400, 16)), 16, rect=(336, 136, 464, 264))
+    stats = {}
+    for cam in ("default", "interior"):
+        with DeviceScene(scenes.sponza_like(RenderConfig(480, 270, 16), camera=cam)) as ds:
+            ds.render(0, 16, pu.SEED, counted=True)
+            stats[cam] = (ds.path_stats(), ds.stats())
+    for ps, st in stats.values():
+        assert ps["samples"] == st["samples"] == 480 * 270 * 16 and abs(sum(ps["rays_per_path_histogram"].values()) - 1.0) < 1e-9
+    assert stats["interior"][0]["primary_hit_fraction"] > 0.999 > stats["default"][0]["primary_hit_fraction"] > 0.5
+    assert stats["interior"][1]["rays"] > 1.15 * stats["default"][1]["rays"]  # (diffuse paths stay short under the reference's estimator: half the bounces draw a light direction, and one below the horizon ends the path)
+    h = stats["default"][0]["rays_per_path_histogram"]
+    mean_lo = h["1"] + 2 * h["2"] + 3 * h["3-4"] + 5 * h["5-8"] + 9 * h["9-16"] + 17 * h["17+"]
+    mean_hi = h["1"] + 2 * h["2"] + 4 * h["3-4"] + 8 * h["5-8"] + 16 * h["9-16"] + 51 * h["17+"]
+    assert mean_lo <= stats["default"][1]["rays"] / stats["default"][1]["samples"] <= mean_hi  # the histogram brackets rays per sample
+
+
 def test_c5_statue_hdri_crop():
     """configs[4] AS BASELINE.json NAMES IT - "+ HDRI env light": the statue stand-in under the procedural HDR environment map
     (EXTENSION, SolSceneDesc::env_*: the reference's miss branch src/renderer/mod.rs:197-204 returns a constant; the direction ->
