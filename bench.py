@@ -89,6 +89,9 @@ def parse_args():
     ap.add_argument("--light", default="", help="with --obj: qx,qy,qz,ux,uy,uz,vx,vy,vz[,r,g,b] Quad light (corner, two edges)")
     ap.add_argument("--hdri", action="store_true", help="c5 only: add the procedural HDR environment map (EXTENSION: the reference has no "
                                                         "environment lights; reported separately from the plain c5 line)")
+    ap.add_argument("--partition", default="balanced", choices=["balanced", "modulo"],
+                    help="N>1: which rank owns an 8x8 block - 'balanced' (default): dealt out by the blocks' cost in the creation probe; "
+                         "'modulo': block b -> rank b mod N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic = null, no roofline_valu)")
@@ -400,6 +403,9 @@ def worker(args):
     if world > 1:
         # the ONE communicator of the run lives behind the C ABI (sol_comm_init: ncclCommInitRank); the store only ships the id
         uid = coord.bcast(bytes(comm_unique_id()) if rank == 0 else None)
+        if args.partition == "balanced":  # blocks dealt out by their cost in the creation probe (every rank derives the same table)
+            from solstrale_amd import _abi
+            ds.set_option(_abi.OPT_BALANCED_PARTITION, 1)
         ds.comm_init(rank, world, uid)
         rccl_ranks = world
     acc = image = None
@@ -470,7 +476,7 @@ def worker(args):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.obj else "user-supplied OBJ",
             "config": {"workload": name, "width": w, "height": h, "spp_total": spp, "pixel_samples_per_gpu": int(w * h * spp // world),
                        "seed": SEED, "max_depth": 50, "scaling_mode": args.scaling,
-                       "sharding": f"8x8 tiles round-robin over {world} rank(s); every rank renders its tiles with all {spp} spp; "
+                       "sharding": f"8x8 tiles " + ("dealt out by probe cost" if (world > 1 and args.partition == "balanced") else "round-robin") + f" over {world} rank(s); every rank renders its tiles with all {spp} spp; "
                                    f"gather to rank 0 " + ("inside the C ABI (sol_gather: grouped ncclSend/ncclRecv)" + (" over the one-GPU test transport stub" if args.rehearse else "")
                                                            if world > 1 else "(single rank: un-permute only)")},
             "mrays_per_s": round(value * rays_per_sample, 2),

@@ -245,11 +245,17 @@ int sol_scene_info(const SolScene* scene, SolSceneInfo* out);
 #define SOL_OPT_FINE_TAIL 5           /* quarters of a 16-sample item per resident lane that the END of a launch hands out one
                                          sample at a time (shorter tail; images unchanged); 0 off, -1 (default) decided by the
                                          creation probe                                                                      */
+#define SOL_OPT_BALANCED_PARTITION 6  /* 1: sol_scene_set_partition / sol_comm_init deal the blocks out by their cost in the creation probe
+                                         (a table behind the partition, the same on every rank) instead of b % world; for runs that use
+                                         sol_gather / sol_read / sol_unpermute of THIS library - a caller with its own collective and
+                                         un-permute keeps the default 0, whose layout it can compute. Set it on every rank, before
+                                         sol_comm_init. Images never depend on it.                                              */
 int sol_scene_set_option(SolScene* scene, int option, int64_t value);
 
 /* Image-tile sharding for one-process-per-GPU runs (no reference analogue). The image is cut
- * into 8x8-pixel blocks, block b (row-major) belongs to rank b % world. Each rank accumulates only its own
- * blocks in a compact buffer of sol_accum_floats() floats: [local_block][py][px][rgb]. Default rank 0/1. */
+ * into 8x8-pixel blocks, block b (row-major) belongs to rank b % world (or, with SOL_OPT_BALANCED_PARTITION, to the rank a
+ * cost-sorted deal gives it). Each rank accumulates only its own blocks in a compact buffer of sol_accum_floats() floats:
+ * [local_block][py][px][rgb]. Default rank 0/1. */
 int sol_scene_set_partition(SolScene* scene, int rank, int world);
 /* A caller-bound accumulator (sol_scene_bind_accum) whose size would change makes this fail with SOL_EINVAL: unbind
  * (sol_scene_bind_accum(scene, NULL, 0)) first, re-bind a buffer of the new sol_accum_floats() afterwards. */

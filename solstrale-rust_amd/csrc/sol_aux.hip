@@ -18,12 +18,16 @@ __global__ void __launch_bounds__(256) sol_resolve_kernel(float* __restrict__ ac
 // compact per-rank tile buffers -> row-major image (row 0 = top). gathered = world buffers of `stride` floats.
 __global__ void __launch_bounds__(256) sol_unpermute_kernel(const float* __restrict__ gathered, float* __restrict__ image,
                                                             uint32_t width, uint32_t height, uint32_t blocks_x, uint32_t world,
-                                                            uint32_t only_rank, size_t stride) {
+                                                            uint32_t only_rank, size_t stride, const uint32_t* __restrict__ slot_of_block) {
   const uint32_t npix = width * height;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
     const uint32_t y = p / width, x = p - y * width;
     const uint32_t b = (y / SOL_TILE) * blocks_x + (x / SOL_TILE);
-    const uint32_t r = b % world, lb = b / world;
+    uint32_t r = b % world, lb = b / world;
+    if (slot_of_block) {  // balanced partition: owner * blocks per buffer + local block
+      const uint32_t per = (uint32_t)(stride / 192u), sl = slot_of_block[b];
+      r = sl / per; lb = sl - r * per;
+    }
     const uint32_t slot = lb * 64u + (y % SOL_TILE) * SOL_TILE + (x % SOL_TILE);
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;
     if (only_rank == 0xFFFFFFFFu || only_rank == r) {
@@ -131,11 +135,11 @@ hipError_t sol_launch_resolve(float* acc, const float* partial, uint32_t n_float
 }
 
 hipError_t sol_launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t blocks_x,
-                                uint32_t world, uint32_t only_rank, size_t stride, hipStream_t stream) {
+                                uint32_t world, uint32_t only_rank, size_t stride, const uint32_t* slot_of_block, hipStream_t stream) {
   uint32_t grid = (width * height + 255u) / 256u;
   if (grid > 4096u) grid = 4096u;
   hipLaunchKernelGGL(sol_unpermute_kernel, dim3(grid), dim3(256), 0, stream, gathered, image, width, height, blocks_x, world,
-                     only_rank, stride);
+                     only_rank, stride, slot_of_block);
   return hipGetLastError();
 }
 

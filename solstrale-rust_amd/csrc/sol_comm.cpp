@@ -114,7 +114,7 @@ int sol_gather(SolScene* s, void* image_dev) {
   if (s->world > 1 && !s->comm) return sol_fail(SOL_EINVAL, "the scene is partitioned %d-way but has no communicator: call sol_comm_init", s->world);
   float* image = image_dev ? (float*)image_dev : s->image;
   if (s->world == 1) {
-    HIP_TRY(sol_launch_unpermute(s->acc, image, s->S.width, s->S.height, s->blocks_x, 1u, 0u, s->acc_floats, s->stream));
+    HIP_TRY(sol_launch_unpermute(s->acc, image, s->S.width, s->S.height, s->blocks_x, 1u, 0u, s->acc_floats, s->slot_of_block, s->stream));
     return SOL_OK;
   }
   Rccl& R = rccl();
@@ -135,7 +135,7 @@ int sol_gather(SolScene* s, void* image_dev) {
       if (e != ncclSuccess) { R.GroupEnd(); return sol_fail(SOL_EDEVICE, "ncclRecv from rank %d: %s", r, R.GetErrorString(e)); }
     }
     RCCL_TRY(R.GroupEnd());
-    HIP_TRY(sol_launch_unpermute(s->gathered, image, s->S.width, s->S.height, s->blocks_x, (uint32_t)s->world, 0xFFFFFFFFu, n, s->stream));
+    HIP_TRY(sol_launch_unpermute(s->gathered, image, s->S.width, s->S.height, s->blocks_x, (uint32_t)s->world, 0xFFFFFFFFu, n, s->slot_of_block, s->stream));
   } else {
     RCCL_TRY(R.Send(s->acc, n, ncclFloat, 0, comm, s->stream));
   }

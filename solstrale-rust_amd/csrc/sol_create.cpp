@@ -625,10 +625,18 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     uint32_t* cost_dev = nullptr;
     HIP_TRY(hipMalloc((void**)&cost_dev, (size_t)nb * sizeof(uint32_t)));
     hipError_t e = hipMemset(cost_dev, 0, (size_t)nb * sizeof(uint32_t));
+    uint32_t* work_dev = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void**)&work_dev, (size_t)nb * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(work_dev, 0, (size_t)nb * sizeof(uint32_t));
     S.block_cost = cost_dev;
+    S.block_work = work_dev;
     rc = e == hipSuccess ? sol_render_impl(s, 0, 4, 0xC057ull, true) : SOL_EDEVICE;
     S.block_cost = nullptr;
+    S.block_work = nullptr;
     s->block_cost.assign(nb, 0u);
+    s->block_work.assign(nb, 0u);
+    if (rc == SOL_OK && hipMemcpy(s->block_work.data(), work_dev, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = SOL_EDEVICE;
+    if (work_dev) hipFree(work_dev);
     if (rc == SOL_OK && hipMemcpy(s->block_cost.data(), cost_dev, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = SOL_EDEVICE;
     hipFree(cost_dev);
     if (rc != SOL_OK) return rc == SOL_EDEVICE ? sol_fail(SOL_EDEVICE, "cost probe failed") : rc;

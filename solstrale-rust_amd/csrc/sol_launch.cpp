@@ -261,7 +261,7 @@ int sol_read_aux(SolScene* s, float* albedo_sum, float* normal_sum) {
   for (int k = 0; k < 2; ++k) {
     if (!outs[k]) continue;
     HIP_TRY(sol_launch_unpermute(s->aux[k], s->image, s->S.width, s->S.height, s->blocks_x, (uint32_t)s->world, (uint32_t)s->rank,
-                                 s->acc_floats, s->stream));
+                                 s->acc_floats, s->slot_of_block, s->stream));
     HIP_TRY(hipMemcpyAsync(outs[k], s->image, (size_t)s->S.width * s->S.height * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   }

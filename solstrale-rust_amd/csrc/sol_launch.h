@@ -23,7 +23,7 @@ size_t sol_wf_pool_bytes(uint32_t slots);
 int sol_wf_lds_stack_depth();
 hipError_t sol_launch_resolve(float* acc, const float* partial, uint32_t n_floats, uint32_t n_chunks, hipStream_t stream);
 hipError_t sol_launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t blocks_x,
-                                uint32_t world, uint32_t only_rank, size_t stride, hipStream_t stream);
+                                uint32_t world, uint32_t only_rank, size_t stride, const uint32_t* slot_of_block, hipStream_t stream);
 hipError_t sol_launch_tonemap(const float* image, uint8_t* rgb, uint32_t n, uint32_t spp, hipStream_t stream);
 // BloomPostProcessor on a W*H*3 fp32 image; a, b: W*H*3 doubles of scratch; rgb == nullptr: result back into `image`
 hipError_t sol_launch_bloom(float* image, double* a, double* b, const double* weights, uint32_t k, uint32_t width, uint32_t height,

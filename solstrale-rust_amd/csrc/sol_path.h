@@ -148,7 +148,7 @@ DEV bool decode_item(const DevScene& S, const RenderParams& P, uint32_t item, It
   it.chunk = item / slots;
   it.slot = item - it.chunk * slots;
   const uint32_t lb = it.slot >> 6, pin = it.slot & 63u;
-  const uint32_t b = lb * P.world + P.rank;
+  const uint32_t b = S.block_of_local ? ldg_u32(S.block_of_local + lb) : lb * P.world + P.rank;
   const uint32_t by = b / P.blocks_x, bx = b - by * P.blocks_x;
   it.px = bx * SOL_TILE + (pin & 7u);
   it.py = by * SOL_TILE + (pin >> 3);
@@ -172,7 +172,7 @@ DEV bool decode_item_ordered(const DevScene& S, const RenderParams& P, uint32_t 
   }
   const uint32_t lb = S.block_order ? ldg_u32(S.block_order + k) : k;
   it.slot = lb * 64u + pin;
-  const uint32_t b = lb * P.world + P.rank;
+  const uint32_t b = S.block_of_local ? ldg_u32(S.block_of_local + lb) : lb * P.world + P.rank;
   const uint32_t by = b / P.blocks_x, bx = b - by * P.blocks_x;
   it.px = bx * SOL_TILE + (pin & 7u);
   it.py = by * SOL_TILE + (pin >> 3);

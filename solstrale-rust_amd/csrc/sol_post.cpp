@@ -24,7 +24,7 @@ int sol_unpermute(SolScene* s, const void* gathered, int world, void* image) {
   if (world != s->world) return sol_fail(SOL_EINVAL, "world %d differs from the scene's partition (%d)", world, s->world);
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(sol_launch_unpermute((const float*)gathered, (float*)image, s->S.width, s->S.height, s->blocks_x, (uint32_t)world,
-                               0xFFFFFFFFu, s->acc_floats, s->stream));
+                               0xFFFFFFFFu, s->acc_floats, s->slot_of_block, s->stream));
   return SOL_OK;
 }
 
@@ -42,7 +42,7 @@ int sol_resolve_image(SolScene* s, void** image_dev) {
   if (!s || !image_dev) return sol_fail(SOL_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(sol_launch_unpermute(s->acc, s->image, s->S.width, s->S.height, s->blocks_x, (uint32_t)s->world, (uint32_t)s->rank,
-                               s->acc_floats, s->stream));
+                               s->acc_floats, s->slot_of_block, s->stream));
   *image_dev = s->image;
   return SOL_OK;
 }

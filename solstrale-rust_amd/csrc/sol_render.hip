@@ -96,7 +96,10 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
             // where it goes was worked out when the item was taken
             float* a = partial + (size_t)out_at * 3;
             a[0] = sum.x; a[1] = sum.y; a[2] = sum.z;
-            if (COUNT && S.block_cost) atomicMax(S.block_cost + (it.slot >> 6), cnt.rays - item_rays0);  // the longest item decides
+            if (COUNT && S.block_cost) {
+              atomicMax(S.block_cost + (it.slot >> 6), cnt.rays - item_rays0);  // work order: the longest item decides
+              atomicAdd(S.block_work + (it.slot >> 6), cnt.rays - item_rays0);  // balanced partition: the block's rays
+            }
             have_item = false;
           }
         }

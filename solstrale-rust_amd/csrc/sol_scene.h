@@ -88,6 +88,11 @@ struct SolScene {
   float* acc_own = nullptr; float* acc = nullptr; size_t acc_floats = 0;
   float* aux[2] = {nullptr, nullptr}; size_t aux_floats = 0;
   std::vector<uint32_t> block_cost;  // per 8x8 block (global index): rays of its longest item in the cost probe; empty: no ordering
+  std::vector<uint32_t> block_work;  // per 8x8 block (global index): its rays in the cost probe (balanced partition)
+  bool balanced = false;             // SOL_OPT_BALANCED_PARTITION
+  std::vector<uint32_t> local_blocks;  // balanced partition: image block of every local block of this rank (empty: b = lb * world + rank)
+  uint32_t* block_of_local_dev = nullptr; size_t block_of_local_cap = 0;
+  uint32_t* slot_of_block = nullptr;   // balanced partition (device, all blocks): owner * blocks-per-buffer + local block; null: modulo
   uint32_t* order_dev = nullptr; size_t order_cap = 0;  // DevScene::block_order of the current partition  // albedo / normal accumulators (sol_render_aux), same layout as acc
   float* partial = nullptr; size_t partial_floats = 0;
   int fine_tail = -1;                // SOL_OPT_FINE_TAIL / SOL_FINE_TAIL: quarters of a whole item per resident lane that the end of a launch hands

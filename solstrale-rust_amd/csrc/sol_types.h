@@ -212,6 +212,11 @@ struct DevScene {
   const uint32_t* block_order;
   uint32_t n_first;
   uint32_t* block_cost;
+  // Tile partition: the image block (row-major over 8x8 blocks) behind local block lb of this rank. null: lb * world + rank (block b
+  // belongs to rank b mod world); a table: the balanced partition (sol_scene_set_option SOL_OPT_BALANCED_PARTITION), the blocks dealt
+  // out in the order of their cost in the creation probe. block_work: where a counted render adds up, per local block, its rays.
+  const uint32_t* block_of_local;
+  uint32_t* block_work;
 };
 
 struct RenderParams {

@@ -127,7 +127,7 @@ def _sig(lib, name, res, args):
 
 
 TREE_AUTO, TREE_REF, TREE_SAH8, TREE_SAH16, TREE_SAH64, TREE_DEVICE, TREE_HOST_PROBE = range(7)
-OPT_SWITCH_BELOW, OPT_MAX_BLOCKS_PER_CU, OPT_KERNEL, OPT_WORK_ORDER, OPT_FINE_TAIL = 1, 2, 3, 4, 5
+OPT_SWITCH_BELOW, OPT_MAX_BLOCKS_PER_CU, OPT_KERNEL, OPT_WORK_ORDER, OPT_FINE_TAIL, OPT_BALANCED_PARTITION = 1, 2, 3, 4, 5, 6
 UNIQUE_ID_BYTES = 128
 
 

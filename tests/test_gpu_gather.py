@@ -37,12 +37,12 @@ def test_stub_exports_what_the_product_binds():
         assert f'sym("{sym}")' in src, sym  # the list above IS what the product binds
 
 
-def run_ranks(world, scene, w, h, spp):
+def run_ranks(world, scene, w, h, spp, balanced=False):
     stub = build_stub()
     with tempfile.TemporaryDirectory(prefix="solgather_") as rdv:
         env = dict(os.environ, LD_LIBRARY_PATH=stub + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), TMPDIR=rdv)
         cmd = [sys.executable, os.path.join(HERE, "tools", "gather_rank.py")]
-        procs = [subprocess.Popen(cmd + [str(r), str(world), rdv, scene, str(w), str(h), str(spp)], env=env, stdout=subprocess.PIPE,
+        procs = [subprocess.Popen(cmd + [str(r), str(world), rdv, scene, str(w), str(h), str(spp)] + (["balanced"] if balanced else []), env=env, stdout=subprocess.PIPE,
                                   stderr=subprocess.STDOUT, text=True) for r in range(world)]
         outs = []
         try:
@@ -58,17 +58,19 @@ def run_ranks(world, scene, w, h, spp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("balanced", [False, True], ids=["b_mod_n", "balanced_table"])
 @pytest.mark.parametrize("world,scene,w,h", [(2, "c3", 256, 128), (3, "c3", 256, 128), (2, "test", 260, 131), (3, "c2", 250, 131), (5, "c1", 97, 61)],
                          ids=["2_ranks", "3_ranks", "2_ranks_odd_block_count_medium", "3_ranks_edge_blocks", "5_ranks_ragged"])
-def test_gather_through_the_abi_equals_the_single_rank_frame(world, scene, w, h):
+def test_gather_through_the_abi_equals_the_single_rank_frame(world, scene, w, h, balanced):
     """Block counts: 256x128 = 512 blocks (2 | 512, 3 does not divide it); 260x131 -> 33 x 17 = 561 (odd); 250x131 -> 32 x 17 =
     544 = 3 * 181 + 1 with padding pixels on two edges; 97x61 -> 13 x 8 = 104 = 5 * 20 + 4. Ranks whose compact buffer has fewer
-    blocks than rank 0's still send rank 0's size (equal counts, sol_scene_set_partition): the receive offsets must match."""
+    blocks than rank 0's still send rank 0's size (equal counts, sol_scene_set_partition): the receive offsets must match. `balanced`:
+    the same with SOL_OPT_BALANCED_PARTITION (blocks dealt out by their cost in the creation probe; the table behind the partition)."""
     spp = 16
     make = {"c1": scenes.cornell_box, "c2": scenes.cornell_spheres, "c3": scenes.sponza_like, "test": scenes.create_test_scene}[scene]
     with DeviceScene(make(RenderConfig(w, h, spp))) as ds:
         ds.render(0, spp, pu.SEED)
         want = ds.read()
-    frames = run_ranks(world, scene, w, h, spp)
+    frames = run_ranks(world, scene, w, h, spp, balanced)
     for k, got in enumerate(frames):
         assert got.shape == want.shape and (got == want).all(), (k, int((got != want).sum()))

@@ -467,11 +467,15 @@ def test_counters_match_definitions():
 
 # ---- multi-GPU sharding on one GPU: every rank's tiles, gathered, equal the single-GPU image ---------------------------
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_tile_partition_is_bit_identical(world):
+@pytest.mark.parametrize("balanced", [0, 1], ids=["b_mod_n", "balanced_table"])
+def test_tile_partition_is_bit_identical(world, balanced):
+    """Block b -> rank b mod world (the default), or - SOL_OPT_BALANCED_PARTITION - the blocks dealt out in the order of their cost in
+    the creation probe: either way every pixel is rendered by exactly one rank, with the sums it has in the single-rank frame."""
     import torch
     sc = scenes.create_test_scene(RenderConfig(203, 97, 20))
     whole = gpu_render(sc, 20)
     with DeviceScene(sc) as ds:
+        ds.set_option(_abi.OPT_BALANCED_PARTITION, balanced)
         ds.set_partition(0, world)
         n = ds.accum_floats()
         gathered = torch.zeros(world * n, dtype=torch.float32, device="cuda")
@@ -484,6 +488,8 @@ def test_tile_partition_is_bit_identical(world):
             part = ds.read()  # other ranks' pixels are zero
             owned = part.any(axis=-1)
             assert (part[owned] == whole[owned]).all()
+            seen = owned.astype(np.int32) if r == 0 else (seen + owned)
+        assert (seen <= 1).all() and seen.sum() >= (whole.any(axis=-1)).sum()  # no pixel twice
         ds.set_partition(0, world)
         image = torch.empty(sc.height * sc.width * 3, dtype=torch.float32, device="cuda")
         ds.unpermute(gathered.data_ptr(), world, image.data_ptr())

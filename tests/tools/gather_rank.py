@@ -2,7 +2,7 @@
 sol_comm_unique_id (rank 0; shipped through a file) -> sol_comm_init -> sol_render -> sol_gather -> rank 0: sol_read_image.
 Every rank uses device 0; the process must find tests/stub_rccl/_build/librccl.so.1 first on LD_LIBRARY_PATH (RCCL itself refuses
 two ranks on one device) and must not load torch (its RCCL would be the one the product's dlopen hands back).
-Usage: python gather_rank.py <rank> <world> <rendezvous dir> <scene> <width> <height> <spp>"""
+Usage: python gather_rank.py <rank> <world> <rendezvous dir> <scene> <width> <height> <spp> [balanced]"""
 import _paths  # noqa: F401  (sys.path)
 import ctypes
 import os
@@ -42,6 +42,9 @@ if __name__ == "__main__":
     if not hasattr(rccl, "sol_stub_rccl_marker"):
         raise SystemExit("the RCCL in this process is not the test stub: LD_LIBRARY_PATH?")
     with DeviceScene(sc, 0) as ds:
+        if len(sys.argv) > 8 and sys.argv[8] == "balanced":
+            from solstrale_amd import _abi
+            ds.set_option(_abi.OPT_BALANCED_PARTITION, 1)  # (every rank, before sol_comm_init)
         ds.comm_init(rank, world, uid)
         for rep in range(2):  # twice: the second gather reuses rank 0's receive buffer
             ds.clear()
