@@ -52,6 +52,7 @@ SolDevOverrides sol_dev_overrides() {
   o.pool_slots = std::max(0, num("SOL_POOL_SLOTS", 0));
   o.wf_slots = std::max(0, num("SOL_WF_SLOTS", 0));
   o.wf_min_items = num("SOL_WF_MIN_ITEMS", -1);
+  o.donate = num("SOL_DONATE", 1) != 0;
   o.verbose = std::getenv("SOL_VERBOSE") != nullptr;
   return o;
 }

@@ -556,6 +556,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
                   (float)c.u[0], (float)c.u[1], (float)c.u[2], (float)c.v[0], (float)c.v[1], (float)c.v[2],
                   (float)c.lens_radius};
   s->kernel_version = ovr.kernel_version;
+  s->donate = ovr.donate;
   s->order_mode = ovr.order_mode;
   // v1's search/shade switch (RenderParams::switch_below), measured on MI355X at 1080p x 128 spp (ms, C1 / C2 / C3 / test scene):
   // 0: 29.2 / 162.9 / 236.7 / 25.9, 8: 27.7 / 124.3 / 193.1 / 25.5, 16: 27.5 / 111.8 / 186.9 / 25.6, 24: 28.6 / 108.6 / 192.3 / 26.8.

@@ -67,6 +67,10 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
 #if SOL_PARK_PATH
   __shared__ float park[6][SOL_WG];
 #endif
+#if SOL_DONATE
+  __shared__ uint32_t donate_pairs[SOL_WG / 64][64];  // per wave: the lanes that give a node group in a hand-out (A/B build)
+  uint32_t turn = 0;
+#endif
 #if SOL_COOP_TRIANGLES
   __shared__ uint32_t coop_queue[SOL_WG / 64][64];  // per wave: the pending triangle tests of a cooperative primitive part (A/B build)
 #else
@@ -174,6 +178,9 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
       if (am != live && (uint32_t)__popcll(am) * 64u < P.switch_below * (uint32_t)__popcll(live)) break;
 #if SOL_WAVE_STEP && !SOL_WORLD_BINARY
       trav_step_wave<COUNT, MEDIUM>(S, t, act, st, (volatile lds_u32*)coop_queue[tid >> 6], p.rng, p.depth, cnt);
+#if SOL_DONATE
+      if (!COUNT && !MEDIUM && !SPILL && P.donate) trav_donate(t, st, (volatile lds_u32*)donate_pairs[tid >> 6], turn++);
+#endif
 #else
       if (act) trav_step<COUNT, MEDIUM, SOL_WORLD_BINARY>(S, t, st, p.rng, p.depth, cnt);
 #endif

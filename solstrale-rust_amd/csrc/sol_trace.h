@@ -648,6 +648,132 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
   t.cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
 }
 
+// ---- Intra-wave donation of pending node groups (-DSOL_DONATE=1) -------------------------------------------------------------
+// In a node part of the search loop 33 of 64 lanes test a node and 24 have FINISHED their search and wait for the wave to leave
+// for the service block (MI355X, C3). With donation such a lane adopts the top stack entry - one node group: the
+// untested siblings of a node - of a lane that is still searching, walks that sub-tree with the donor's ray (gathered through
+// ds_bpermute) and the donor's best t of that moment as its cull distance, and hands its closest hit back; the donor merges it by
+// the (t, dfs) rule of `better`. The closest hit does not depend on who searches which sub-tree or with which cull distance (every
+// candidate is either found or beaten by something found: DESIGN.md 4, "tree independence"), so frames stay bit-identical.
+//   status of a 7-wide search in t.cur:  0 running | CUR_LENT own search with a group out (running or exhausted: then the lane
+//   waits) | CUR_HELP + donor lane: walking a stolen group | CUR_HELP_FIN + donor lane: that walk is over, result to deliver |
+//   REF_DONE.
+// No extra LDS: the helper's own finished search (ray, hit: 10 dwords - the service block needs them) is parked in the top ten
+// entries of ITS OWN stack column, which is empty (its search is over; the stolen sub-tree needs at most bound - 2 entries); the
+// mailbox (valid, t, ref, dfs, u, v) is the top six entries of the DONOR's column. The host enables donation only for trees whose
+// stack bound leaves that room (RenderParams::donate), never for counted launches (the counters would depend on scheduling) and
+// never for scenes with constant media (their nested boundary searches use the column above t.sp).
+#define CUR_LENT 1u
+#define CUR_HELP 0x100u
+#define CUR_HELP_FIN 0x200u
+#define SOL_PARK_AT (SOL_LDS_STACK - 10)  // first entry of a helper's parked search in its own column
+#define SOL_MAIL_AT (SOL_LDS_STACK - 6)   // first entry of the mailbox in a donor's column
+#define SOL_DONATE_BOUND (SOL_LDS_STACK - 8)  // largest stack bound of a tree that may donate: mailbox above the donor's own entries, and
+                                              // a stolen group (level >= 1: bound - 2) below the helper's parked search
+DEV void trav_out_of_work(Trav& t) {
+#if SOL_DONATE
+  if (t.cur & CUR_HELP) t.cur ^= (CUR_HELP | CUR_HELP_FIN);  // -> CUR_HELP_FIN + donor: delivered by trav_donate in this turn
+  else if (t.cur != CUR_LENT) t.cur = REF_DONE;              // (CUR_LENT: wait for the helper)
+#else
+  t.cur = REF_DONE;
+#endif
+}
+#if SOL_DONATE
+#ifndef SOL_DONATE_MIN
+#define SOL_DONATE_MIN 8   // lanes that must be waiting with a finished search before groups are handed out
+#endif
+#ifndef SOL_DONATE_EVERY
+#define SOL_DONATE_EVERY 2  // the hand-out is considered every 2^n-th turn of the search loop
+#endif
+// Called by every lane of the wave after a step. pair: 64 dwords of LDS of this wave (donor lane of the k-th pair).
+DEV void trav_donate(Trav& t, const Stack& st, volatile lds_u32* pair, uint32_t turn) {
+  const uint32_t lane = __lane_id();
+  volatile lds_u32* const mine = (volatile lds_u32*)st.lds;
+  // ---- delivery: helpers whose stolen group is exhausted write their hit into the donor's mailbox and take their own finished
+  // search back; lanes with a group out look into their mailbox
+  const bool fin = t.cur != REF_DONE && (t.cur & CUR_HELP_FIN) != 0u;
+  if (sol_ballot(fin) != 0ull) {
+    if (fin) {
+      volatile lds_u32* const box = mine - lane + (t.cur & 63u);
+      box[(SOL_MAIL_AT + 1) * SOL_WG] = __float_as_uint(t.h.t);
+      box[(SOL_MAIL_AT + 2) * SOL_WG] = t.h.ref;
+      box[(SOL_MAIL_AT + 3) * SOL_WG] = t.h.dfs;
+      box[(SOL_MAIL_AT + 4) * SOL_WG] = __float_as_uint(t.h.u);
+      box[(SOL_MAIL_AT + 5) * SOL_WG] = __float_as_uint(t.h.v);
+      box[(SOL_MAIL_AT + 0) * SOL_WG] = 1u;
+      t.o.x = __uint_as_float(mine[(SOL_PARK_AT + 0) * SOL_WG]); t.o.y = __uint_as_float(mine[(SOL_PARK_AT + 1) * SOL_WG]);
+      t.o.z = __uint_as_float(mine[(SOL_PARK_AT + 2) * SOL_WG]); t.d.x = __uint_as_float(mine[(SOL_PARK_AT + 3) * SOL_WG]);
+      t.d.y = __uint_as_float(mine[(SOL_PARK_AT + 4) * SOL_WG]); t.d.z = __uint_as_float(mine[(SOL_PARK_AT + 5) * SOL_WG]);
+      t.h.t = __uint_as_float(mine[(SOL_PARK_AT + 6) * SOL_WG]); t.h.ref = mine[(SOL_PARK_AT + 7) * SOL_WG];
+      t.h.u = __uint_as_float(mine[(SOL_PARK_AT + 8) * SOL_WG]); t.h.v = __uint_as_float(mine[(SOL_PARK_AT + 9) * SOL_WG]);
+      t.g0 = 0u; t.pg = 0u; t.sp = t.sp_base = 0;
+      t.cur = REF_DONE;
+    }
+    if (t.cur == CUR_LENT && mine[SOL_MAIL_AT * SOL_WG] != 0u) {
+      const float tt = __uint_as_float(mine[(SOL_MAIL_AT + 1) * SOL_WG]);
+      const uint32_t ref = mine[(SOL_MAIL_AT + 2) * SOL_WG], dfs = mine[(SOL_MAIL_AT + 3) * SOL_WG];
+      const float u = __uint_as_float(mine[(SOL_MAIL_AT + 4) * SOL_WG]), v = __uint_as_float(mine[(SOL_MAIL_AT + 5) * SOL_WG]);
+      if (SOL_REF_KIND(ref) != SOL_REF_NONE && better(tt, dfs, t.h)) { t.h.t = tt; t.h.ref = ref; t.h.dfs = dfs; t.h.u = u; t.h.v = v; }
+      t.cur = 0u;
+      if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
+    }
+  }
+  // ---- hand-out: the k-th waiting lane takes the top stack entry of the k-th lane that has one to give
+  if ((turn & ((1u << SOL_DONATE_EVERY) - 1u)) != 0u) return;
+  const bool idle = t.cur == REF_DONE;
+  const unsigned long long idle_m = sol_ballot(idle);
+  if ((int)__popcll(idle_m) < SOL_DONATE_MIN) return;
+  const bool giver = t.cur == 0u && t.sp - t.sp_base >= 2;
+  const unsigned long long giver_m = sol_ballot(giver);
+  if (giver_m == 0ull) return;
+  const uint32_t n_pairs = min((uint32_t)__popcll(idle_m), (uint32_t)__popcll(giver_m));
+  const uint32_t rank_i = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+  const uint32_t rank_g = __builtin_amdgcn_mbcnt_hi((uint32_t)(giver_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)giver_m, 0u));
+  const bool gives = giver && rank_g < n_pairs, takes = idle && rank_i < n_pairs;
+  if (gives) {
+    mine[SOL_MAIL_AT * SOL_WG] = 0u;
+#if SOL_DONATE_BOTTOM  // the OLDEST entry: the far siblings of a shallow node - a large sub-tree, but the one a near hit would have culled
+    pair[rank_g] = lane | ((uint32_t)(t.sp_base + 2) << 8);
+    t.sp_base += 2;
+#else                  // the newest entry: what the donor would have searched next
+    pair[rank_g] = lane | ((uint32_t)t.sp << 8);
+    t.sp -= 2;  // (the entry stays where it is until the helper has read it: nothing is pushed before the next step)
+#endif
+    t.cur = CUR_LENT;
+  }
+  const uint32_t e = takes ? pair[rank_i] : lane;
+  const uint32_t from = e & 63u, from4 = from << 2;
+  // (every lane executes the gathers: a bpermute reads registers of enabled lanes only)
+  const uint32_t ox = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.o.x)), oy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.o.y));
+  const uint32_t oz = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.o.z)), dx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.d.x));
+  const uint32_t dy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.d.y)), dz = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.d.z));
+  const uint32_t ix = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.inv.x)), iy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.inv.y));
+  const uint32_t iz = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.inv.z)), bt = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.h.t));
+  const uint32_t oc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)t.oct);
+  if (takes) {
+    mine[(SOL_PARK_AT + 0) * SOL_WG] = __float_as_uint(t.o.x); mine[(SOL_PARK_AT + 1) * SOL_WG] = __float_as_uint(t.o.y);
+    mine[(SOL_PARK_AT + 2) * SOL_WG] = __float_as_uint(t.o.z); mine[(SOL_PARK_AT + 3) * SOL_WG] = __float_as_uint(t.d.x);
+    mine[(SOL_PARK_AT + 4) * SOL_WG] = __float_as_uint(t.d.y); mine[(SOL_PARK_AT + 5) * SOL_WG] = __float_as_uint(t.d.z);
+    mine[(SOL_PARK_AT + 6) * SOL_WG] = __float_as_uint(t.h.t); mine[(SOL_PARK_AT + 7) * SOL_WG] = t.h.ref;
+    mine[(SOL_PARK_AT + 8) * SOL_WG] = __float_as_uint(t.h.u); mine[(SOL_PARK_AT + 9) * SOL_WG] = __float_as_uint(t.h.v);
+    volatile lds_u32* const col = mine - lane + from;
+    const uint32_t at = (e >> 8) - 2u;
+    t.g0 = col[at * SOL_WG];
+    t.g1 = col[(at + 1u) * SOL_WG];
+    t.pg = 0u;
+    t.sp = t.sp_base = 0;
+    t.o = mk3(__uint_as_float(ox), __uint_as_float(oy), __uint_as_float(oz));
+    t.d = mk3(__uint_as_float(dx), __uint_as_float(dy), __uint_as_float(dz));
+    t.inv = mk3(__uint_as_float(ix), __uint_as_float(iy), __uint_as_float(iz));
+    t.oct = oc;
+    t.h.t = __uint_as_float(bt);
+    t.h.ref = SOL_MAKE_REF(SOL_REF_NONE, 0);
+    t.h.dfs = 0u;
+    t.cur = CUR_HELP | from;
+  }
+}
+#endif  // SOL_DONATE
+
 // One step of a 7-wide world search for a whole WAVE (every lane of the wave calls it; `act`: the lane has a running search) - the
 // product kernel's form of trav_step: the same two parts, but the votes on the step's shape (does any lane hold primitives? are
 // they postponed?) are taken by the whole wave once instead of inside the divergent region of the searching lanes
@@ -668,11 +794,16 @@ DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, v
                         Counters& cnt) {
   if (act) {
     phase_tick<COUNT>(cnt, 0);
+#if SOL_DONATE
+    // (a lane whose own search is exhausted while a group of it is out with a helper stays in the loop without work)
+    if ((t.pg >> 24) == 0u && ((t.g0 >> 24) != 0u || t.sp != t.sp_base)) wide_visit<COUNT>(t, st, cnt);
+#else
     if ((t.pg >> 24) == 0u) wide_visit<COUNT>(t, st, cnt);
+#endif
   }
   const bool has_prim = act && (t.pg >> 24) != 0u;
   const bool has_inner = act && !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);
-  if (act && !has_prim && !has_inner) t.cur = REF_DONE;
+  if (act && !has_prim && !has_inner) trav_out_of_work(t);
   const unsigned long long prim_m = sol_ballot(has_prim);
   if (prim_m == 0ull) return;
 #if SOL_PRIM_MIN > 1
@@ -696,7 +827,7 @@ DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, v
       }
       prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
     }
-    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
+    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) trav_out_of_work(t);
   }
 #if SOL_COOP_TRIANGLES
   const bool tri_owner = has_prim && lkind == SOL_LEAF_TRIANGLES;

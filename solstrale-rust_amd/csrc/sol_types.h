@@ -46,6 +46,12 @@
 #ifndef SOL_PARK_PATH
 #define SOL_PARK_PATH 0           // product kernel: the path's throughput registers (A, C) live in LDS during a search (sol_render.hip)
 #endif
+#ifndef SOL_DONATE
+#define SOL_DONATE 0              // 1: A/B build - intra-wave donation of pending node groups (sol_trace.h, trav_donate)
+#endif
+#ifndef SOL_DONATE_BOTTOM
+#define SOL_DONATE_BOTTOM 0
+#endif
 #ifndef SOL_COOP_TRIANGLES
 #define SOL_COOP_TRIANGLES 0      // 1: A/B build - the wave's pending triangle tests dealt out over all its lanes (trav_step_wave; measured slower)
 #endif
@@ -238,6 +244,7 @@ struct RenderParams {
   uint32_t n_coarse;
   uint32_t fine_count;       // samples of the last chunk (1 .. 16): fine items with sub >= fine_count do not exist
   uint32_t stage_at;
+  uint32_t donate;           // 1: finished lanes adopt node groups of searching lanes of their wave (sol_trace.h, trav_donate; -DSOL_DONATE builds)
 };
 
 struct DevCounters {
