@@ -481,6 +481,8 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   // references into them (DevTree); candidate 0 first, the others only if a probe has to decide
   const bool need_binary = SOL_WORLD_BINARY || d->n_mediums > 0;  // the 2-wide tree serves medium boundaries (and the A/B build) only
   auto upload_tree = [&](TreeCand& c) -> int {
+    // (the node test reads plane bytes as the fp16 subnormals q * 2^-24 and keeps the 2^24 in the node scales: sol_trace.h)
+    if (c.emin + 31u + 24u > 254u) return sol_fail(SOL_EINVAL, "the scene is too large for the quantised world tree (extent beyond 2^100)");
     const WideLayout& L = c.lay;
     DevTree& t = c.dev;
     std::vector<DTri> ptris(tris.size());

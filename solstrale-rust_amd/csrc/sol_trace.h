@@ -89,7 +89,7 @@ DEV void sol_search_context(Stack& st, const DevScene& S) {
   if (PIN) asm volatile("" : "+v"(w), "+v"(e));  // (the triangle pointer too would cost the kernel its last registers: 3 spills)
   st.wides = (const DWide*)w;
   st.tris = (const DTri*)tr;
-  st.wide_emin = e;
+  st.wide_emin = e + (SOL_CLAMP_SLABS ? 24u : 0u);  // (the clamped node test reads plane bytes as the halves q * 2^-24)
   st.oct_table = nullptr;
   st.oct_table_on = false;
 }
@@ -287,8 +287,11 @@ DEV float sol_min_raw(float a, float b) {
 #define SOL_FMA_MIX_HI(d, h2, b, a) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(d) : "v"(h2), "v"(b), "v"(a))
 #define SOL_FMA_MIX_x SOL_FMA_MIX_LO
 #define SOL_FMA_MIX_y SOL_FMA_MIX_HI
-typedef uint32_t sol_h2;  // two halves (1024 + q0, 1024 + q1): v_perm_b32 puts two plane bytes under the fp16 exponent of 1024
-#define SOL_H2(w, sel) __builtin_amdgcn_perm(0x64646464u, (w), (sel))
+// Two plane bytes become two halves by ONE byte permute that puts a zero byte above each: the fp16 SUBNORMALS q * 2^-24, exact, which
+// v_fma_mix_f32 takes as its first factor (fp16 denormals are enabled in the kernel's float mode); the node's scales carry the 2^24
+// (sol_search_context: wide_emin + 24), so t = q * B + A with a single rounding - no offset of 1024 to take out of the addend again.
+typedef uint32_t sol_h2;
+#define SOL_H2(w, sel) __builtin_amdgcn_perm(0u, (w), (sel) | 0x0C000C00u)
 #define SOL_WIDE_CHILD(i, hnx, hny, hnz, hfx, hfy, hfz, e)                                                             \
   {                                                                                                                     \
     float tnx, tfx, tny, tfy, tnz, tfz;                                                                                 \
@@ -368,8 +371,10 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
 #if SOL_HALF_PLANES || SOL_CLAMP_SLABS
   {
+#if !SOL_CLAMP_SLABS
     const float ax0 = ax, ay0 = ay, az0 = az;
     const float ax = fmaf(-1024.0f, bx, ax0), ay = fmaf(-1024.0f, by, ay0), az = fmaf(-1024.0f, bz, az0);  // (shadow the plain addends)
+#endif
     const sol_h2 hnx01 = SOL_H2(nx0, 0x04010400u), hnx23 = SOL_H2(nx0, 0x04030402u), hnx45 = SOL_H2(nx1, 0x04010400u), hnx6 = SOL_H2(nx1, 0x04030402u);
     const sol_h2 hny01 = SOL_H2(ny0, 0x04010400u), hny23 = SOL_H2(ny0, 0x04030402u), hny45 = SOL_H2(ny1, 0x04010400u), hny6 = SOL_H2(ny1, 0x04030402u);
     const sol_h2 hnz01 = SOL_H2(nz0, 0x04010400u), hnz23 = SOL_H2(nz0, 0x04030402u), hnz45 = SOL_H2(nz1, 0x04010400u), hnz6 = SOL_H2(nz1, 0x04030402u);
