@@ -38,8 +38,8 @@ def _stale(target, deps):
 
 
 def _run(cmd):
-    print("+", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=HERE)
+    print("+", " ".join(cmd), file=sys.stderr, flush=True)  # (never stdout: bench.py's stdout is ONE JSON line)
+    subprocess.check_call(cmd, cwd=HERE, stdout=sys.stderr)
 
 
 def build(force=False, extra_hip_flags=(), out_dir=None, ab_kernels=False):
