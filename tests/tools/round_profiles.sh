@@ -19,6 +19,7 @@ if [[ $part == *b* ]]; then
   run c2 --workload c2
   run c4 --workload c4 --steps 2
   run c5 --workload c5 --steps 2
+  run c5_pmc512 --workload c5 --steps 1 --warmup 0 --pmc-spp 512 --no-cpu-baseline   # (a launch 8 times longer under the counters: its tail weighs an eighth)
   run c5_hdri --workload c5 --hdri --steps 2 --no-cpu-baseline
   run c3_interior --workload c3 --camera-preset interior --no-cpu-baseline
   run c5_closeup --workload c5 --camera-preset closeup --steps 2 --no-cpu-baseline
