@@ -75,6 +75,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
   __shared__ uint32_t coop_queue[SOL_WG / 64][64];  // per wave: the pending triangle tests of a cooperative primitive part (A/B build)
 #else
   lds_u32* const coop_queue[SOL_WG / 64] = {};
+  (void)coop_queue;
 #endif
 
   for (;;) {
