@@ -82,7 +82,44 @@ def build_ab(force=False):
     return build(force=force, out_dir=BUILD_AB, ab_kernels=True)
 
 
+# The experiments of DESIGN.md 9 that were built, keep every frame bit-identical and are SLOWER: kept compilable and under test
+# (tests/test_gpu_parity.py::test_rejected_experiments_keep_every_frame) as variants of the one translation unit they live in.
+EXPERIMENTS = {"donate": ["-DSOL_DONATE=1"], "coop_triangles": ["-DSOL_COOP_TRIANGLES=1"], "round2_step": ["-DSOL_WAVE_STEP=0", "-DSOL_CLAMP_SLABS=0"]}
+BUILD_EXP = os.path.join(HERE, "_build_exp")
+
+
+def build_experiments(force=False):
+    """_build_exp/<name>/: the product library with sol_render.hip re-compiled under the experiment's macros (the other objects are
+    the product's own). Call after build()."""
+    import shutil
+    base_objs = [os.path.join(BUILD, os.path.basename(src) + ".o") for src in HIP_SRC if not src.endswith("sol_render.hip")]
+    jobs, libs = [], []
+    for name, extra in EXPERIMENTS.items():
+        out = os.path.join(BUILD_EXP, name)
+        os.makedirs(out, exist_ok=True)
+        obj, lib = os.path.join(out, "sol_render.hip.o"), os.path.join(out, "libsolstrale_hip.so")
+        flags_file = os.path.join(out, "hip_flags.txt")
+        want = " ".join(HIP_FLAGS + extra)
+        if force or _stale(obj, ["csrc/sol_render.hip"] + HIP_HDR + ["build.py"]) or not os.path.exists(flags_file) or open(flags_file).read() != want:
+            jobs.append([HIPCC] + HIP_FLAGS + extra + ["-c", "csrc/sol_render.hip", "-o", obj])
+        libs.append((obj, lib, flags_file, want, out))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(_run, jobs))
+    for obj, lib, flags_file, want, out in libs:
+        deps = [obj] + base_objs
+        if not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in deps):
+            _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", obj] + base_objs + ["-o", lib, "-ldl"])
+        open(flags_file, "w").write(want)
+        host = os.path.join(out, "libsolstrale_host.so")  # (finds the device library beside it: RUNPATH $ORIGIN)
+        src_host = os.path.join(BUILD, "libsolstrale_host.so")
+        if not os.path.exists(host) or os.path.getmtime(src_host) > os.path.getmtime(host):
+            shutil.copy2(src_host, host)
+    return [l[1] for l in libs]
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     if "--ab" in sys.argv:
         build_ab(force="--force" in sys.argv)
+        build_experiments(force="--force" in sys.argv)
