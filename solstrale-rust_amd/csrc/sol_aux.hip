@@ -93,6 +93,65 @@ __global__ void __launch_bounds__(256) sol_bloom_blur_kernel(const double* __res
     out[(size_t)p * 3] = cx; out[(size_t)p * 3 + 1] = cy; out[(size_t)p * 3 + 2] = cz;
   }
 }
+// The same blur, LDS-tiled (round 3): one workgroup owns SOL_BLUR_TILE consecutive outputs of one row, loads them and their k - 1
+// neighbours ONCE into LDS (coordinates clamped to the row: get_pixel_safe) and every thread forms SOL_BLUR_PER_THREAD adjacent outputs
+// from it - an input value read from LDS feeds that many accumulators. Each output is still  col += pixel * w[i]  for i = 0 .. k-1
+// in this order, in f64: bit-identical to the kernel above (tests/test_post.py compares both with the numpy restatement). The
+// vertical pass runs as transpose -> the same row kernel -> transpose (two 200-MB copies at 4K against k-fold strided reads).
+// MI355X, tests/tools/bloom_bench.py: 4K, k = 1537: 40.9 -> see DESIGN.md 3.
+#define SOL_BLUR_PER_THREAD 4
+#define SOL_BLUR_TILE (256 * SOL_BLUR_PER_THREAD)
+#define SOL_BLUR_MAX_K 1665  // (SOL_BLUR_TILE + k - 1) * 24 bytes must fit 64 KiB of LDS; longer kernels use the untiled form
+__global__ void __launch_bounds__(256) sol_bloom_blur_rows_kernel(const double* __restrict__ in, double* __restrict__ out, uint32_t width,
+                                                                  uint32_t height, const double* __restrict__ weights, uint32_t k) {
+  extern __shared__ double tile[];  // (SOL_BLUR_TILE + k - 1) pixels x 3
+  const int half = (int)(k / 2);
+  const uint32_t tiles_x = (width + SOL_BLUR_TILE - 1) / SOL_BLUR_TILE;
+  const uint32_t row = blockIdx.x / tiles_x, x0 = (blockIdx.x - row * tiles_x) * SOL_BLUR_TILE;
+  const uint32_t span = SOL_BLUR_TILE + k - 1;
+  const double* src = in + (size_t)row * width * 3;
+  for (uint32_t j = threadIdx.x; j < span; j += 256u) {
+    const int sx = min(max((int)x0 + (int)j - half, 0), (int)width - 1);
+    tile[3 * j] = src[(size_t)sx * 3]; tile[3 * j + 1] = src[(size_t)sx * 3 + 1]; tile[3 * j + 2] = src[(size_t)sx * 3 + 2];
+  }
+  __syncthreads();
+  // thread t forms outputs x0 + t + 256 * m, m = 0 .. PER_THREAD-1 (adjacent threads, adjacent LDS addresses)
+  double acc[SOL_BLUR_PER_THREAD][3];
+#pragma unroll
+  for (int m = 0; m < SOL_BLUR_PER_THREAD; ++m) acc[m][0] = acc[m][1] = acc[m][2] = 0.0;
+  for (uint32_t i = 0; i < k; ++i) {
+    const double w = weights[i];
+#pragma unroll
+    for (int m = 0; m < SOL_BLUR_PER_THREAD; ++m) {
+      const double* s = tile + 3 * (threadIdx.x + 256u * m + i);
+      acc[m][0] = acc[m][0] + s[0] * w; acc[m][1] = acc[m][1] + s[1] * w; acc[m][2] = acc[m][2] + s[2] * w;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < SOL_BLUR_PER_THREAD; ++m) {
+    const uint32_t x = x0 + threadIdx.x + 256u * m;
+    if (x < width) {
+      double* o = out + ((size_t)row * width + x) * 3;
+      o[0] = acc[m][0]; o[1] = acc[m][1]; o[2] = acc[m][2];
+    }
+  }
+}
+// out[x][y] = in[y][x] for W x H pixels of three doubles (32 x 32 tiles through LDS)
+__global__ void __launch_bounds__(256) sol_transpose3_kernel(const double* __restrict__ in, double* __restrict__ out, uint32_t width, uint32_t height) {
+  __shared__ double t[32][33 * 3];
+  const uint32_t bx = blockIdx.x * 32u, by = blockIdx.y * 32u, tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
+  for (uint32_t r = ty; r < 32u; r += 8u)
+    if (bx + tx < width && by + r < height) {
+      const double* s = in + ((size_t)(by + r) * width + bx + tx) * 3;
+      t[r][3 * tx] = s[0]; t[r][3 * tx + 1] = s[1]; t[r][3 * tx + 2] = s[2];
+    }
+  __syncthreads();
+  for (uint32_t r = ty; r < 32u; r += 8u)
+    if (by + tx < height && bx + r < width) {
+      double* o = out + ((size_t)(bx + r) * height + by + tx) * 3;
+      o[0] = t[tx][3 * r]; o[1] = t[tx][3 * r + 1]; o[2] = t[tx][3 * r + 2];
+    }
+}
 // 4. pixel + blurred (bloom.rs:144-148); then either back to the fp32 image (intermediate_post_process, rounded to fp32:
 // the device keeps fp32 sums) or straight through to_rgb_color in f64 (post_process).
 __global__ void __launch_bounds__(256) sol_bloom_finish_kernel(float* __restrict__ image, const double* __restrict__ blurred,
@@ -119,8 +178,21 @@ hipError_t sol_launch_bloom(float* image, double* a, double* b, const double* we
   if (grid > 8192u) grid = 8192u;
   if (grid == 0) return hipSuccess;
   hipLaunchKernelGGL(sol_bloom_bright_kernel, dim3(grid), dim3(256), 0, stream, image, a, npix, threshold, max_intensity);
-  hipLaunchKernelGGL((sol_bloom_blur_kernel<false>), dim3(grid), dim3(256), 0, stream, a, b, width, height, weights, k);
-  hipLaunchKernelGGL((sol_bloom_blur_kernel<true>), dim3(grid), dim3(256), 0, stream, b, a, width, height, weights, k);
+  static const bool untiled = false;  // (the untiled kernels remain for kernels longer than SOL_BLUR_MAX_K taps)
+  if (!untiled && k <= SOL_BLUR_MAX_K) {
+    const size_t lds = (size_t)(SOL_BLUR_TILE + k - 1) * 3 * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void*)sol_bloom_blur_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) return e;
+    const uint32_t tiles_w = (width + SOL_BLUR_TILE - 1) / SOL_BLUR_TILE, tiles_h = (height + SOL_BLUR_TILE - 1) / SOL_BLUR_TILE;
+    // rows: a -> b; columns: b^T (= a) -> rows of the transposed image -> b, transposed back -> a
+    hipLaunchKernelGGL(sol_bloom_blur_rows_kernel, dim3(tiles_w * height), dim3(256), lds, stream, a, b, width, height, weights, k);
+    hipLaunchKernelGGL(sol_transpose3_kernel, dim3((width + 31u) / 32u, (height + 31u) / 32u), dim3(256), 0, stream, b, a, width, height);
+    hipLaunchKernelGGL(sol_bloom_blur_rows_kernel, dim3(tiles_h * width), dim3(256), lds, stream, a, b, height, width, weights, k);
+    hipLaunchKernelGGL(sol_transpose3_kernel, dim3((height + 31u) / 32u, (width + 31u) / 32u), dim3(256), 0, stream, b, a, height, width);
+  } else {
+    hipLaunchKernelGGL((sol_bloom_blur_kernel<false>), dim3(grid), dim3(256), 0, stream, a, b, width, height, weights, k);
+    hipLaunchKernelGGL((sol_bloom_blur_kernel<true>), dim3(grid), dim3(256), 0, stream, b, a, width, height, weights, k);
+  }
   hipLaunchKernelGGL(sol_bloom_finish_kernel, dim3(grid), dim3(256), 0, stream, image, a, rgb, npix * 3u, spp);
   return hipGetLastError();
 }

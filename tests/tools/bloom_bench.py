@@ -20,4 +20,4 @@ for w, h in ((1920, 1080), (3840, 2160)):
             dt = (time.perf_counter() - t) / 3
             taps = 2 * k * w * h * 3  # f64 multiply-adds of the two blur passes
             print(f"{w}x{h} kernel_size {k:4d}: {dt * 1e3:8.2f} ms  {taps / dt / 1e12:6.2f} T f64 FMA/s  "
-                  f"{2 * k * w * h * 24 / dt / 1e12:6.2f} TB/s of L1/L2-served tap reads", flush=True)
+                  f"{2 * k * w * h * 24 / dt / 1e12:6.2f} TB/s of tap reads (LDS-tiled blur: served by LDS)", flush=True)
