@@ -97,7 +97,9 @@ def test_device_bloom_matches_oracle_on_the_reference_input():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("w,h,frac,thr,maxi,spp", [(64, 48, 0.1, None, None, 1), (37, 23, 0.5, 2.5, 6., 3), (129, 65, 0., 1., None, 7),
-                                                  (320, 180, 0.25, None, 4., 16)])
+                                                  (320, 180, 0.25, None, 4., 16),
+                                                  (1100, 9, 0.3, None, None, 2),   # two row tiles of the LDS-tiled blur, a ragged second one (k = 661)
+                                                  (1700, 5, 0.5, 1.5, None, 1)])   # k = 1701 > 1665 taps: the untiled blur
 def test_device_bloom_intermediate_and_final_are_exact(w, h, frac, thr, maxi, spp):
     import torch
     p = _hdr(w, h, w * 1000 + h) * spp
