@@ -26,8 +26,13 @@ HIP_HDR = ["csrc/sol_types.h", "csrc/sol_math.h", "csrc/sol_trace.h", "csrc/sol_
 HOST_SRC = ["host/solstrale_host.cpp", "host/solstrale_obj.cpp", "host/solstrale_host_c.cpp"]
 HOST_DEPS = HOST_SRC + ["host/solstrale.hpp", "../include/solstrale_hip.h", "../include/solstrale_host.h"]
 
+# -packed-fp32-ops (target feature OFF): hipcc otherwise pairs fp32 multiplies and adds into v_pk_mul_f32 / v_pk_add_f32 /
+# v_pk_fma_f32 wherever it finds two alike (cross products of the triangle test, shading vectors). On MI355X a packed instruction
+# issues like two (4.8 cycles: tests/tools/micro/valu_ops.hip) and its operands must sit in aligned register pairs: the render
+# kernel paid for the pairing in moves and in its only 6 VGPR spills. Without them: 0 spills, C1 -5.9 %, C2 -4.8 %, C3 -3.5 %
+# (profiles/r03_no_packed_fp32_ab.txt); the arithmetic is the same IEEE operations either way (every frame CRC identical).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-             "-Wall", "-Wno-unused-value"]
+             "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Wall", "-Wno-unused-value"]
 
 
 def _stale(target, deps):
