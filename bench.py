@@ -541,6 +541,8 @@ def worker(args):
                 "unit": "G wave64-instr/s x lane utilisation", "frac": round(inst_per_s * lane_util / peak_inst, 5),
                 "valu_instr_per_sample": round(g("SQ_INSTS_VALU", 0.0) / p_samples, 1), "lane_utilisation": round(lane_util, 4),
                 "issue_busy_at_4_cycles_per_instr": round(busy4, 4), "issue_frac_of_2_cycle_peak": round(inst_per_s / peak_inst, 4),
+                "issue_note": "SQ_ACTIVE_INST_VALU x 4 cycles / SIMD cycles: 1.0 = every vector instruction took one 4-cycle issue slot and every slot was "
+                              "taken; above 1.0 (since the build without packed fp32 instructions) the plain fp32 multiplies / adds issue at their faster rate",
                 "wave_cycles_waiting_frac": round(g("SQ_WAIT_ANY", 0.0) / max(1.0, g("SQ_WAVE_CYCLES", 0.0)), 4),
                 "clock_ghz": round(clock / 1e9, 3), "kernel_ms_under_pmc": round(info * 1e-6, 3), "pmc_spp": p_spp}
     if rank == 0:
