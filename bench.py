@@ -232,7 +232,7 @@ def launch_ranks(args):
     stdout is ours); any rank failing fails the run (the others are terminated: a lost rank would hang their collective)."""
     if not args.no_build:
         import __graft_entry__
-        __graft_entry__.build()  # once, here: the ranks must not race on the build (compiles and dlopens only, no GPU call)
+        __graft_entry__.build_product()  # once, here: the ranks must not race on the build (compiles and dlopens only, no GPU call)
     server = _StoreServer()  # (the listening socket exists from here on: no port to lose between choosing and using it)
     server.start()
     extra = {}
@@ -374,11 +374,10 @@ def worker(args):
     if not args.rehearse:
         import torch
     if rank == 0 and not args.no_build:
-        __graft_entry__.build()
+        __graft_entry__.build_product()  # (the product libraries; the A/B library and the oracle are built where they are used)
     coord = Coord(rank, world)
     coord.barrier()
-    if rank != 0 and not args.no_build:
-        __graft_entry__.build()  # no-op when up to date; loads the libraries
+    # every other rank only LOADS what rank 0 built (or what --no-build promises is there): no second writer in the build directory
     if args.rehearse:
         local_rank = 0
     from solstrale_amd import DeviceScene, RenderConfig, comm_unique_id, device_count, record_sizes

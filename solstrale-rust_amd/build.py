@@ -7,8 +7,9 @@ hipcc cross-compiles gfx950 code objects without a GPU. -ffp-contract=off keeps 
 IEEE sequence the parity tests pin (DESIGN.md "fp32 arithmetic contract"). Translation units are compiled in
 parallel to objects (only the stale ones) and linked; `build(out_dir=..., extra_hip_flags=...)` makes an A/B variant
 of the device library elsewhere (tests/tools/variants.py), selected at run time through SOLSTRALE_BUILD_DIR.
-`build_ab()` makes _build_ab/: the same library plus the two wavefront render-kernel variants (-DSOL_AB_KERNELS), which the
-product library does not carry.
+`build_ab()` makes _build_ab/: the same library plus the two wavefront render-kernel variants (-DSOL_AB_KERNELS +
+csrc/sol_wavefront.hip), which the product library does not carry. Rejected experiments are not kept in the sources: their records
+are profiles/*_ab.txt and the git history.
 """
 import os
 import subprocess
@@ -57,9 +58,11 @@ def build(force=False, extra_hip_flags=(), out_dir=None, ab_kernels=False):
     flags_file = os.path.join(out_dir, "hip_flags.txt")
     flags = HIP_FLAGS + (["-DSOL_AB_KERNELS"] if ab_kernels else []) + list(extra_hip_flags)
     sources = HIP_SRC + (["csrc/sol_wavefront.hip"] if ab_kernels else [])
-    if not os.path.exists(flags_file) or open(flags_file).read() != " ".join(flags + sources):
+    want = " ".join(flags + sources)
+    have = open(flags_file).read() if os.path.exists(flags_file) else None
+    if have != want:
         force = True
-        if os.path.exists(flags_file):
+        if have is not None:
             os.remove(flags_file)  # (written again only after a successful link: an interrupted build starts over)
     jobs, objs = [], []
     for src in sources:
@@ -73,7 +76,11 @@ def build(force=False, extra_hip_flags=(), out_dir=None, ab_kernels=False):
     # link whenever an object is newer than the library (also after a failed or interrupted link of an earlier run)
     if jobs or not os.path.exists(hip_lib) or any(os.path.getmtime(o) > os.path.getmtime(hip_lib) for o in objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", hip_lib, "-ldl"])
-    open(flags_file, "w").write(" ".join(flags + sources))
+    if force or have != want:  # (only when something was built, and atomically: ranks of one job may call build() side by side)
+        tmp = flags_file + f".{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            f.write(want)
+        os.replace(tmp, flags_file)
     if force or _stale(host_lib, HOST_DEPS + ["build.py"]) or os.path.getmtime(hip_lib) > os.path.getmtime(host_lib):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-pthread"] + HOST_SRC +
              ["-o", host_lib, "-L" + out_dir, "-lsolstrale_hip", "-Wl,-rpath,$ORIGIN"])
@@ -87,44 +94,7 @@ def build_ab(force=False):
     return build(force=force, out_dir=BUILD_AB, ab_kernels=True)
 
 
-# The experiments of DESIGN.md 9 that were built, keep every frame bit-identical and are SLOWER: kept compilable and under test
-# (tests/test_gpu_parity.py::test_rejected_experiments_keep_every_frame) as variants of the one translation unit they live in.
-EXPERIMENTS = {"donate": ["-DSOL_DONATE=1"], "coop_triangles": ["-DSOL_COOP_TRIANGLES=1"], "round2_step": ["-DSOL_WAVE_STEP=0", "-DSOL_CLAMP_SLABS=0"]}
-BUILD_EXP = os.path.join(HERE, "_build_exp")
-
-
-def build_experiments(force=False):
-    """_build_exp/<name>/: the product library with sol_render.hip re-compiled under the experiment's macros (the other objects are
-    the product's own). Call after build()."""
-    import shutil
-    base_objs = [os.path.join(BUILD, os.path.basename(src) + ".o") for src in HIP_SRC if not src.endswith("sol_render.hip")]
-    jobs, libs = [], []
-    for name, extra in EXPERIMENTS.items():
-        out = os.path.join(BUILD_EXP, name)
-        os.makedirs(out, exist_ok=True)
-        obj, lib = os.path.join(out, "sol_render.hip.o"), os.path.join(out, "libsolstrale_hip.so")
-        flags_file = os.path.join(out, "hip_flags.txt")
-        want = " ".join(HIP_FLAGS + extra)
-        if force or _stale(obj, ["csrc/sol_render.hip"] + HIP_HDR + ["build.py"]) or not os.path.exists(flags_file) or open(flags_file).read() != want:
-            jobs.append([HIPCC] + HIP_FLAGS + extra + ["-c", "csrc/sol_render.hip", "-o", obj])
-        libs.append((obj, lib, flags_file, want, out))
-    if jobs:
-        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
-            list(ex.map(_run, jobs))
-    for obj, lib, flags_file, want, out in libs:
-        deps = [obj] + base_objs
-        if not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in deps):
-            _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", obj] + base_objs + ["-o", lib, "-ldl"])
-        open(flags_file, "w").write(want)
-        host = os.path.join(out, "libsolstrale_host.so")  # (finds the device library beside it: RUNPATH $ORIGIN)
-        src_host = os.path.join(BUILD, "libsolstrale_host.so")
-        if not os.path.exists(host) or os.path.getmtime(src_host) > os.path.getmtime(host):
-            shutil.copy2(src_host, host)
-    return [l[1] for l in libs]
-
-
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     if "--ab" in sys.argv:
         build_ab(force="--force" in sys.argv)
-        build_experiments(force="--force" in sys.argv)

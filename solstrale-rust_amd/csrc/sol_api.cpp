@@ -52,7 +52,6 @@ SolDevOverrides sol_dev_overrides() {
   o.pool_slots = std::max(0, num("SOL_POOL_SLOTS", 0));
   o.wf_slots = std::max(0, num("SOL_WF_SLOTS", 0));
   o.wf_min_items = num("SOL_WF_MIN_ITEMS", -1);
-  o.donate = num("SOL_DONATE", 1) != 0;
   o.verbose = std::getenv("SOL_VERBOSE") != nullptr;
   return o;
 }
@@ -173,7 +172,7 @@ int sol_device_count(void) {
 }
 
 int sol_record_sizes(uint32_t out[6]) {
-  out[0] = SOL_WORLD_BINARY ? sizeof(DNode) : sizeof(DWide); out[1] = sizeof(DSphere); out[2] = sizeof(DQuad); out[3] = sizeof(DTri);
+  out[0] = sizeof(DWide); out[1] = sizeof(DSphere); out[2] = sizeof(DQuad); out[3] = sizeof(DTri);
   out[4] = sizeof(DTriShade); out[5] = sizeof(DMat);
   return SOL_OK;
 }

@@ -293,7 +293,6 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   Box root_box;
   if (!tb.resolve(d->root, 0, root_ref, root_box)) return sol_fail(SOL_EINVAL, "world: %s", tb.error.c_str());
   if (SOL_REF_KIND(root_ref) == SOL_REF_NONE) return sol_fail(SOL_EINVAL, "world is empty");
-  const uint32_t world_depth = tb.max_depth;
   std::vector<DMedium> mediums(d->n_mediums);
   uint32_t medium_depth = 0;
   for (uint32_t i = 0; i < d->n_mediums; ++i) {
@@ -336,7 +335,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   };
   std::vector<TreeCand> cands;
   // stack entries (dwords): a wide level keeps at most one sibling group of two dwords
-  auto depth_of = [&](const WideLayout& l) { return (SOL_WORLD_BINARY ? world_depth : 2u * l.depth) + medium_depth + 2; };
+  auto depth_of = [&](const WideLayout& l) { return 2u * l.depth + medium_depth + 2; };
   const uint32_t stack_limit = SOL_LDS_STACK + SOL_SPILL_STACK;
   // AUTO = the device build: as good a tree as the probed host candidates (node visits per ray, host probe / device: C2 11.0 /
   // 10.9, C3 12.8 / 13.0, C5 6.8 / 6.9) in a sixth to an eighth of the time (sol_scene_create, C3: 0.40 s -> 0.06 s, C5 2.2 s -> 0.3 s)
@@ -476,10 +475,10 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
       s->build_times[0] += seconds_since(t_host0);
     }
   }
-  const bool calibrate = cands.size() > 1 && !SOL_WORLD_BINARY && !device_build;
+  const bool calibrate = cands.size() > 1 && !device_build;
   // everything that depends on the choice of the world tree: the tree itself, the permuted primitive arrays and every table of
   // references into them (DevTree); candidate 0 first, the others only if a probe has to decide
-  const bool need_binary = SOL_WORLD_BINARY || d->n_mediums > 0;  // the 2-wide tree serves medium boundaries (and the A/B build) only
+  const bool need_binary = d->n_mediums > 0;  // the 2-wide tree serves medium boundaries only
   auto upload_tree = [&](TreeCand& c) -> int {
     // (the node test reads plane bytes as the fp16 subnormals q * 2^-24 and keeps the 2^24 in the node scales: sol_trace.h)
     if (c.emin + 31u + 24u > 254u) return sol_fail(SOL_EINVAL, "the scene is too large for the quantised world tree (extent beyond 2^100)");
@@ -558,7 +557,6 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
                   (float)c.u[0], (float)c.u[1], (float)c.u[2], (float)c.v[0], (float)c.v[1], (float)c.v[2],
                   (float)c.lens_radius};
   s->kernel_version = ovr.kernel_version;
-  s->donate = ovr.donate;
   s->order_mode = ovr.order_mode;
   // v1's search/shade switch (RenderParams::switch_below), measured on MI355X at 1080p x 128 spp (ms, C1 / C2 / C3 / test scene):
   // 0: 29.2 / 162.9 / 236.7 / 25.9, 8: 27.7 / 124.3 / 193.1 / 25.5, 16: 27.5 / 111.8 / 186.9 / 25.6, 24: 28.6 / 108.6 / 192.3 / 26.8.

@@ -35,8 +35,6 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   P.n_items = (uint32_t)items;
   if (P.n_items == 0) return SOL_OK;
   P.switch_below = s->switch_below;
-  // (-DSOL_DONATE builds) donation needs room above the searches' own entries in every stack column: sol_trace.h
-  P.donate = (!count && !s->has_medium && s->tree_depth <= (uint32_t)(SOL_LDS_STACK - 8) && s->donate) ? 1u : 0u;
   // Kernel choice. The product library carries ONE render kernel family, the one-path-per-lane kernel (version 1); the two
   // wavefront variants (2: wave-private pool, 3: two-kernel wavefront; bit-identical images) exist in -DSOL_AB_KERNELS builds for
   // A/B runs: they raise the search's lane occupancy (0.45 -> 0.67-0.73) but pay for it in state traffic, refill stalls and

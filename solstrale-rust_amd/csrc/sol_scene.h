@@ -54,7 +54,6 @@ struct SolDevOverrides {
   int max_bpc = -1;              // SOL_MAX_BPC
   int fine_tail = -2;            // SOL_FINE_TAIL (-2: not set)
   int pool_slots = 0, wf_slots = 0, wf_min_items = -1;  // SOL_POOL_SLOTS / SOL_WF_SLOTS / SOL_WF_MIN_ITEMS (v2 / v3)
-  bool donate = true;            // SOL_DONATE=0: no donation of node groups in a -DSOL_DONATE build (A/B within one library)
   bool verbose = false;          // SOL_VERBOSE
 };
 SolDevOverrides sol_dev_overrides();
@@ -122,7 +121,6 @@ struct SolScene {
   uint32_t last_rounds = 0; int last_version = 0;
   double build_times[4] = {0., 0., 0., 0.};  // sol_scene_build_times
   bool order_enabled = true;         // SOL_OPT_WORK_ORDER
-  bool donate = true;                // (SOL_DONATE=0 switches donation off in a -DSOL_DONATE build)
   int order_mode = 2;                // (SOL_ORDER) 1: heavy blocks first only; 2: + cost classes within a chunk
   int max_bpc = 0;                   // SOL_OPT_MAX_BLOCKS_PER_CU (0 = what the occupancy query allows)
   // multi-GPU (sol_comm_init): RCCL communicator of the tile partition and rank 0's receive buffer

@@ -13,9 +13,8 @@
 #include "sol_math.h"
 #include "sol_types.h"
 
-// The world (searches with t >= 0.001) is walked through the 7-wide quantised tree; -DSOL_WORLD_BINARY=true builds the
-// A/B variant that walks the 2-wide DNode tree instead (same results).
-#define SOL_WORLD_ROOT(S) (SOL_WORLD_BINARY ? (S).root : (S).wroot)
+// The world (searches with t >= 0.001) is walked through the 7-wide quantised tree (DWide); the boundary searches of a constant
+// medium, whose interval includes negative t, walk the reference-shaped 2-wide tree (DNode).
 
 #define REF_DONE 0xFFFFFFFFu
 #define ALMOST_ZERO_F 1e-8f  // src/geo/vec3.rs:21
@@ -39,9 +38,6 @@ struct Counters {
 // wave counts the 64 slots of this execution.
 template <bool COUNT>
 DEV void phase_tick(Counters& cnt, int ph) {
-#ifdef SOL_PROBE_STEP
-  return;  // (probe build: the six counters describe the two parts of a search step instead, see trav_step)
-#endif
   if (COUNT) {
     cnt.phase[2 * ph]++;
     const unsigned long long m = sol_ballot(true);
@@ -89,7 +85,7 @@ DEV void sol_search_context(Stack& st, const DevScene& S) {
   if (PIN) asm volatile("" : "+v"(w), "+v"(e));  // (the triangle pointer too would cost the kernel its last registers: 3 spills)
   st.wides = (const DWide*)w;
   st.tris = (const DTri*)tr;
-  st.wide_emin = e + (SOL_CLAMP_SLABS ? 24u : 0u);  // (the clamped node test reads plane bytes as the halves q * 2^-24)
+  st.wide_emin = e + 24u;  // (the node test reads plane bytes as the halves q * 2^-24: the scales carry the 2^24)
   st.oct_table = nullptr;
   st.oct_table_on = false;
 }
@@ -267,14 +263,7 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
 // B = scale * inv  (one FMA per plane), and the near / far byte arrays of each axis are chosen once per node from the sign of
 // the ray direction. This is NOT the reference's (b - o) * inv sequence and need not be: the boxes are culls, and the
 // builder pads them by twice the fp32 box pad, three times the worst rounding error of this evaluation.
-// NaN (0 * inf for axis-parallel rays) is ignored by fmaxf / fminf, i.e. treated as "no constraint": conservative.
-// v_min_f32 as it is: fminf on a value the compiler cannot prove canonical (cull_t, built from bits) costs a v_max x, x first
-DEV float sol_min_raw(float a, float b) {
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-#if SOL_CLAMP_SLABS
+//
 // The slab parameters are evaluated in units of the cull distance, t' = t / min(best t, 1e30): the search interval is then [0, 1]
 // and the CLAMP output modifier of the plane FMAs does what a maximum with 0 (near planes) and a minimum with the cull distance
 // (far planes) did - two of the twelve vector instructions per child. A child must be visited iff te' < tx', STRICTLY: a box wholly
@@ -303,36 +292,6 @@ typedef uint32_t sol_h2;
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tx) : "v"(tfx), "v"(tfy), "v"(tfz));                                         \
     miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(te - tx), 31u); /* (here: the HIT bits: sign of te - tx) */   \
   }
-#elif SOL_HALF_PLANES
-// Plane bytes become floats two at a time: v_perm_b32 puts two bytes of a plane word under the fp16 exponent of 1024 - the halves
-// (1024 + q0, 1024 + q1), exact - and v_fma_mix_f32 takes a half as its first factor: t = (1024 + q) * B + (A - 1024 * B). 24 + 42
-// vector instructions per node instead of 42 conversions + 42 FMAs, and the kernel's time follows its vector instruction count
-// (DESIGN.md 3). The shifted addend costs one more rounding, |A - 1024 B| * 2^-24: the builder's extra pad covers it (sol_tree.h).
-typedef _Float16 sol_h2 __attribute__((ext_vector_type(2)));
-#define SOL_H2(w, sel) __builtin_bit_cast(sol_h2, __builtin_amdgcn_perm(0x64646464u, (w), (sel)))
-#define SOL_WIDE_CHILD(i, hnx, hny, hnz, hfx, hfy, hfz, e)                                                             \
-  {                                                                                                                     \
-    const float tnx = fmaf((float)hnx.e, bx, ax), tfx = fmaf((float)hfx.e, bx, ax);                                     \
-    const float tny = fmaf((float)hny.e, by, ay), tfy = fmaf((float)hfy.e, by, ay);                                     \
-    const float tnz = fmaf((float)hnz.e, bz, az), tfz = fmaf((float)hfz.e, bz, az);                                     \
-    const float te = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));                                                         \
-    const float tx = fminf(fminf(tfx, tfy), sol_min_raw(tfz, cull_t));                                                  \
-    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tx - te), 31u);                                              \
-  }
-#else
-#define SOL_WIDE_CHILD(i, nxw, nyw, nzw, fxw, fyw, fzw, refv)                                                          \
-  {                                                                                                                     \
-    const float tnx = fmaf((float)(((nxw) >> (8 * ((i) & 3))) & 0xFFu), bx, ax), tfx = fmaf((float)(((fxw) >> (8 * ((i) & 3))) & 0xFFu), bx, ax); \
-    const float tny = fmaf((float)(((nyw) >> (8 * ((i) & 3))) & 0xFFu), by, ay), tfy = fmaf((float)(((fyw) >> (8 * ((i) & 3))) & 0xFFu), by, ay); \
-    const float tnz = fmaf((float)(((nzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az), tfz = fmaf((float)(((fzw) >> (8 * ((i) & 3))) & 0xFFu), bz, az); \
-    const float te = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));                                                         \
-    const float tx = fminf(fminf(tfx, tfy), sol_min_raw(tfz, cull_t));                                                        \
-    /* te <= tx as the sign of tx - te, shifted into the mask: a subtraction and one alignbit instead of compare, select and */ \
-    /* or. te is in [0, inf], tx in [-inf, FLT_MAX] (cull_t is finite), so the difference is never NaN; tx = -0 counts as a  */ \
-    /* miss, which it is for a search with tmin > 0. An empty slot has an inverted box: a miss.                             */ \
-    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tx - te), 31u);                                                \
-  }
-#endif
 // The slab tests of one fetched 7-wide node (h = origin + meta, qa / qb / qc = the six plane arrays) for the ray of search `t`:
 // the search's new node group and primitive group.
 template <bool COUNT>
@@ -342,25 +301,13 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   const uint32_t meta = __float_as_uint(h.w);
   const float scx = __uint_as_float(((meta & 31u) + wide_emin) << 23), scy = __uint_as_float((((meta >> 5) & 31u) + wide_emin) << 23);
   const float scz = __uint_as_float((((meta >> 10) & 31u) + wide_emin) << 23);
-#ifdef SOL_NO_TCULL
-  const float cull_t = 3.402823466e38f;
-#else
-  // t >= tmin > 0 in a world search; made finite (see SOL_WIDE_CHILD) by an unsigned minimum of the bit patterns: best t is a
-  // positive float or +inf, never NaN, and one instruction where fminf takes two (canonicalise, then minimum)
-  const float cull_t = __uint_as_float(min(__float_as_uint(t.h.t), 0x7F7FFFFFu));
-#endif
   uint32_t miss = 0u;  // children are tested 6 .. 0, each shifting its bit in at the bottom: child i ends on bit i
   // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
   // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
   // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
-#if SOL_CLAMP_SLABS
   // (units of the cull distance, a millionth short: see SOL_WIDE_CHILD; best t is a positive float or +inf, never NaN)
   const float rc = __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(t.h.t, RAY_MIN_F, 1e30f) * 1.000001f);
-  (void)cull_t;
   const float ivx = t.inv.x * rc, ivy = t.inv.y * rc, ivz = t.inv.z * rc;  // (t.inv: clamped to +-1e30 by trav_begin)
-#else
-  const float ivx = t.inv.x, ivy = t.inv.y, ivz = t.inv.z;
-#endif
   const float ax = (h.x - t.o.x) * ivx, bx = scx * ivx;
   const float ay = (h.y - t.o.y) * ivy, by = scy * ivy;
   const float az = (h.z - t.o.z) * ivz, bz = scz * ivz;
@@ -369,12 +316,7 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   const uint32_t nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
   const uint32_t ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
   const uint32_t nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
-#if SOL_HALF_PLANES || SOL_CLAMP_SLABS
   {
-#if !SOL_CLAMP_SLABS
-    const float ax0 = ax, ay0 = ay, az0 = az;
-    const float ax = fmaf(-1024.0f, bx, ax0), ay = fmaf(-1024.0f, by, ay0), az = fmaf(-1024.0f, bz, az0);  // (shadow the plain addends)
-#endif
     const sol_h2 hnx01 = SOL_H2(nx0, 0x04010400u), hnx23 = SOL_H2(nx0, 0x04030402u), hnx45 = SOL_H2(nx1, 0x04010400u), hnx6 = SOL_H2(nx1, 0x04030402u);
     const sol_h2 hny01 = SOL_H2(ny0, 0x04010400u), hny23 = SOL_H2(ny0, 0x04030402u), hny45 = SOL_H2(ny1, 0x04010400u), hny6 = SOL_H2(ny1, 0x04030402u);
     const sol_h2 hnz01 = SOL_H2(nz0, 0x04010400u), hnz23 = SOL_H2(nz0, 0x04030402u), hnz45 = SOL_H2(nz1, 0x04010400u), hnz6 = SOL_H2(nz1, 0x04030402u);
@@ -389,20 +331,7 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
     SOL_WIDE_CHILD(1, hnx01, hny01, hnz01, hfx01, hfy01, hfz01, y)
     SOL_WIDE_CHILD(0, hnx01, hny01, hnz01, hfx01, hfy01, hfz01, x)
   }
-#else
-  SOL_WIDE_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, 0)
-  SOL_WIDE_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, 0)
-  SOL_WIDE_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, 0)
-  SOL_WIDE_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-  SOL_WIDE_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-  SOL_WIDE_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-  SOL_WIDE_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
-#endif
-#if SOL_CLAMP_SLABS
   const uint32_t hits = miss;  // (the clamped form shifts in HIT bits)
-#else
-  const uint32_t hits = ~miss;
-#endif
   const uint32_t imask = (meta >> 15) & 0x7Fu, lmask = (meta >> 22) & 0x7Fu;
   // inner hits into visit order: bit p <- bit p ^ octant (three conditional butterfly stages)
   uint32_t ih = hits & imask;
@@ -508,105 +437,14 @@ DEV void wide_visit(Trav& t, const Stack& st, Counters& cnt) {
   asm volatile("s_setprio %0" ::"n"(SOL_LOOP_PRIO) : "memory");  // (after the loads are issued; asm: the builtin may be moved across them)
 #endif
   if (COUNT) cnt.node_visits++;
-#if defined(SOL_EXP_VMEM) || defined(SOL_EXP_VALU) || defined(SOL_EXP_LDS)
-  // Sensitivity probes (A/B builds only, tests/tools/variants.py): extra work per node visit that changes no result -
-  // SOL_EXP_VMEM more 16-byte loads of this node (L1 hits), SOL_EXP_VALU more vector instructions, SOL_EXP_LDS more LDS stores -
-  // to see which pipe the kernel's time follows.
-  {
-    uint32_t zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-#ifdef SOL_EXP_VMEM
-#pragma unroll
-    for (int k = 0; k < SOL_EXP_VMEM; ++k) { const uint4 x = ldg_u4(wp + zero + (k % 4)); asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
-#endif
-#ifdef SOL_EXP_VALU
-    float dummy = h.x;
-#pragma unroll
-    for (int k = 0; k < SOL_EXP_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy));
-    asm volatile("" ::"v"(dummy));
-#endif
-#ifdef SOL_EXP_LDS
-#pragma unroll
-    for (int k = 0; k < SOL_EXP_LDS; ++k) st.lds[(SOL_LDS_STACK - 1) * SOL_WG] = zero;  // (top level: scratch unless the stack is full)
-#endif
-  }
-#endif
   wide_node_test<COUNT>(st, t, oct, h, qa, qb, qc);
 }
 
-// One step of a search. BINARY selects which tree this search walks: the 2-wide DNode tree (constant-medium boundaries,
-// whose search interval includes negative t) or the 7-wide DWide tree (the world).
-//   2-wide: visits the node or primitive t.cur, then moves to the next reference (near child, or popped from the stack).
-//   7-wide: part 1 - a lane without pending primitives takes the nearest child of its node group (popping a group first when
-//   its own is used up), pushes the rest of the group, fetches that node (64 bytes) and tests its seven child boxes: a new node
-//   group and a new primitive group. Part 2 - a lane with pending primitives tests ONE of them. A lane so advances by up to
-//   two visits per step, while a wave whose lanes are spread over nodes and primitives pays for both parts anyway.
-template <bool COUNT, bool MEDIUM, bool BINARY>
-DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
+// One step of a search of the 2-wide DNode tree (the boundary of a constant medium, whose interval includes negative t): visits
+// the node or primitive t.cur, then moves to the next reference (near child, or popped from the stack).
+template <bool COUNT>
+DEV void boundary_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
   phase_tick<COUNT>(cnt, 0);
-  if (!BINARY) {
-#ifdef SOL_PROBE_STEP
-    // probe build (tests/tools/variants.py, perf_quick --phases): [0] lanes in node parts, [1] 64 per node part executed by the
-    // wave, [2] / [3] the same for primitive parts, [4] lanes holding primitives while a node part runs, [5] of those, the
-    // lanes whose primitive part is then postponed
-    if (COUNT) {
-      const bool node_lane = (t.pg >> 24) == 0u;
-      const unsigned long long nm = sol_ballot(node_lane);
-      if (nm != 0ull) {
-        if (node_lane) cnt.phase[0]++; else cnt.phase[4]++;
-        if ((int)__lane_id() == __ffsll((long long)sol_ballot(true)) - 1) cnt.phase[1] += 64u;
-      }
-    }
-#endif
-    if ((t.pg >> 24) == 0u) wide_visit<COUNT>(t, st, cnt);
-    // status for the callers' loops, and for the postponing rule below
-    const bool has_prim = (t.pg >> 24) != 0u;
-    const bool has_inner = !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);
-#if SOL_PRIM_MIN > 1
-    // Postponed primitive tests: the lanes holding primitives wait while fewer than SOL_PRIM_MIN of the wave's lanes do and
-    // some lane still has an inner node to visit next turn; the primitive part then runs with more lanes enabled. Results do
-    // not depend on the order of the tests.
-    const unsigned long long inner_m = sol_ballot(has_inner), prim_m = sol_ballot(has_prim);
-    if (!has_prim && !has_inner) { t.cur = REF_DONE; return; }
-    if (!has_prim) return;
-#ifdef SOL_PROBE_STEP
-    if (COUNT && inner_m != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) cnt.phase[5]++;
-#endif
-    if (inner_m != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) return;
-#else
-    if (!has_prim && !has_inner) { t.cur = REF_DONE; return; }
-    if (!has_prim) return;
-#endif
-#ifdef SOL_PROBE_STEP
-    if (COUNT) {
-      cnt.phase[2]++;
-      if ((int)__lane_id() == __ffsll((long long)sol_ballot(true)) - 1) cnt.phase[3] += 64u;
-    }
-#endif
-    const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
-    t.pg &= ~(1u << (24u + slot));
-    const uint32_t lkind = t.g1 >> 29;  // (no group was popped since this node's test: a lane with pending primitives skips part 1)
-    uint32_t idx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(t.g1, 22u, slot));  // lmask bits below `slot`
-    // Triangle leaves go straight to their test: through prim_test's chain (leaf kind -> reference kind -> compare tree) every
-    // test had nine more vector instructions in front of it. MI355X, 64 spp, ms: C3 74.8 -> 73.3; a direct path for EVERY leaf
-    // kind was no better (C3 73.8, C1 10.75 against 10.57 / 10.67): the other kinds keep the chain.
-#if SOL_LEAF_KIND_DISPATCH == 1
-    if (lkind == SOL_LEAF_TRIANGLES) {
-      triangle_prim_test<COUNT>(t, st, idx, cnt);
-    } else
-#endif
-    {
-      uint32_t kind = lkind == SOL_LEAF_TRIANGLES ? SOL_REF_TRIANGLE : lkind == SOL_LEAF_SPHERES ? SOL_REF_SPHERE : SOL_REF_QUAD;
-      if (lkind == SOL_LEAF_REFS) {  // mixed node: the reference is listed
-        const uint32_t r = ldg_u32(S.leaf_refs + idx);
-        kind = SOL_REF_KIND(r);
-        idx = SOL_REF_INDEX(r);
-      }
-      prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
-    }
-    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
-    return;
-  }
   uint32_t cur = t.cur;
   uint32_t kind = SOL_REF_KIND(cur);
   if (kind == SOL_REF_NODE) {
@@ -619,11 +457,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     // Culling: a box whose entry parameter lies beyond the best hit cannot hold a better one. The slab test clamps the
     // entry to 0 (origin inside the box), and a search over (-inf, inf) (constant-medium boundary) accepts hits at
     // negative t, so boxes entered at 0 are never culled.
-#ifdef SOL_NO_TCULL
-    const float cull_t = __builtin_huge_valf();
-#else
     const float cull_t = fmaxf(t.h.t, 0.0f);
-#endif
     float tl, tr;
     bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, t.o, t.inv, sx, sy, sz, tl) && tl <= cull_t;
     bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, t.o, t.inv, sx, sy, sz, tr) && tr <= cull_t;
@@ -649,179 +483,40 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
     kind = SOL_REF_KIND(cur);
   }
   if (cur == REF_DONE || kind == SOL_REF_NODE) { t.cur = cur; return; }
-  prim_test<COUNT, MEDIUM>(S, t, st, kind, SOL_REF_INDEX(cur), rng, depth, cnt);
+  prim_test<COUNT, false>(S, t, st, kind, SOL_REF_INDEX(cur), rng, depth, cnt);
   t.cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
 }
 
-// ---- Intra-wave donation of pending node groups (-DSOL_DONATE=1) -------------------------------------------------------------
-// In a node part of the search loop 33 of 64 lanes test a node and 24 have FINISHED their search and wait for the wave to leave
-// for the service block (MI355X, C3). With donation such a lane adopts the top stack entry - one node group: the
-// untested siblings of a node - of a lane that is still searching, walks that sub-tree with the donor's ray (gathered through
-// ds_bpermute) and the donor's best t of that moment as its cull distance, and hands its closest hit back; the donor merges it by
-// the (t, dfs) rule of `better`. The closest hit does not depend on who searches which sub-tree or with which cull distance (every
-// candidate is either found or beaten by something found: DESIGN.md 4, "tree independence"), so frames stay bit-identical.
-//   status of a 7-wide search in t.cur:  0 running | CUR_LENT own search with a group out (running or exhausted: then the lane
-//   waits) | CUR_HELP + donor lane: walking a stolen group | CUR_HELP_FIN + donor lane: that walk is over, result to deliver |
-//   REF_DONE.
-// No extra LDS: the helper's own finished search (ray, hit: 10 dwords - the service block needs them) is parked in the top ten
-// entries of ITS OWN stack column, which is empty (its search is over; the stolen sub-tree needs at most bound - 2 entries); the
-// mailbox (valid, t, ref, dfs, u, v) is the top six entries of the DONOR's column. The host enables donation only for trees whose
-// stack bound leaves that room (RenderParams::donate), never for counted launches (the counters would depend on scheduling) and
-// never for scenes with constant media (their nested boundary searches use the column above t.sp).
-#define CUR_LENT 1u
-#define CUR_HELP 0x100u
-#define CUR_HELP_FIN 0x200u
-#define SOL_PARK_AT (SOL_LDS_STACK - 10)  // first entry of a helper's parked search in its own column
-#define SOL_MAIL_AT (SOL_LDS_STACK - 6)   // first entry of the mailbox in a donor's column
-#define SOL_DONATE_BOUND (SOL_LDS_STACK - 8)  // largest stack bound of a tree that may donate: mailbox above the donor's own entries, and
-                                              // a stolen group (level >= 1: bound - 2) below the helper's parked search
-DEV void trav_out_of_work(Trav& t) {
-#if SOL_DONATE
-  if (t.cur & CUR_HELP) t.cur ^= (CUR_HELP | CUR_HELP_FIN);  // -> CUR_HELP_FIN + donor: delivered by trav_donate in this turn
-  else if (t.cur != CUR_LENT) t.cur = REF_DONE;              // (CUR_LENT: wait for the helper)
-#else
-  t.cur = REF_DONE;
-#endif
-}
-#if SOL_DONATE
-#ifndef SOL_DONATE_MIN
-#define SOL_DONATE_MIN 8   // lanes that must be waiting with a finished search before groups are handed out
-#endif
-#ifndef SOL_DONATE_EVERY
-#define SOL_DONATE_EVERY 2  // the hand-out is considered every 2^n-th turn of the search loop
-#endif
-// Called by every lane of the wave after a step. pair: 64 dwords of LDS of this wave (donor lane of the k-th pair).
-DEV void trav_donate(Trav& t, const Stack& st, volatile lds_u32* pair, uint32_t turn) {
-  const uint32_t lane = __lane_id();
-  volatile lds_u32* const mine = (volatile lds_u32*)st.lds;
-  // ---- delivery: helpers whose stolen group is exhausted write their hit into the donor's mailbox and take their own finished
-  // search back; lanes with a group out look into their mailbox
-  const bool fin = t.cur != REF_DONE && (t.cur & CUR_HELP_FIN) != 0u;
-  if (sol_ballot(fin) != 0ull) {
-    if (fin) {
-      volatile lds_u32* const box = mine - lane + (t.cur & 63u);
-      box[(SOL_MAIL_AT + 1) * SOL_WG] = __float_as_uint(t.h.t);
-      box[(SOL_MAIL_AT + 2) * SOL_WG] = t.h.ref;
-      box[(SOL_MAIL_AT + 3) * SOL_WG] = t.h.dfs;
-      box[(SOL_MAIL_AT + 4) * SOL_WG] = __float_as_uint(t.h.u);
-      box[(SOL_MAIL_AT + 5) * SOL_WG] = __float_as_uint(t.h.v);
-      box[(SOL_MAIL_AT + 0) * SOL_WG] = 1u;
-      t.o.x = __uint_as_float(mine[(SOL_PARK_AT + 0) * SOL_WG]); t.o.y = __uint_as_float(mine[(SOL_PARK_AT + 1) * SOL_WG]);
-      t.o.z = __uint_as_float(mine[(SOL_PARK_AT + 2) * SOL_WG]); t.d.x = __uint_as_float(mine[(SOL_PARK_AT + 3) * SOL_WG]);
-      t.d.y = __uint_as_float(mine[(SOL_PARK_AT + 4) * SOL_WG]); t.d.z = __uint_as_float(mine[(SOL_PARK_AT + 5) * SOL_WG]);
-      t.h.t = __uint_as_float(mine[(SOL_PARK_AT + 6) * SOL_WG]); t.h.ref = mine[(SOL_PARK_AT + 7) * SOL_WG];
-      t.h.u = __uint_as_float(mine[(SOL_PARK_AT + 8) * SOL_WG]); t.h.v = __uint_as_float(mine[(SOL_PARK_AT + 9) * SOL_WG]);
-      t.g0 = 0u; t.pg = 0u; t.sp = t.sp_base = 0;
-      t.cur = REF_DONE;
-    }
-    if (t.cur == CUR_LENT && mine[SOL_MAIL_AT * SOL_WG] != 0u) {
-      const float tt = __uint_as_float(mine[(SOL_MAIL_AT + 1) * SOL_WG]);
-      const uint32_t ref = mine[(SOL_MAIL_AT + 2) * SOL_WG], dfs = mine[(SOL_MAIL_AT + 3) * SOL_WG];
-      const float u = __uint_as_float(mine[(SOL_MAIL_AT + 4) * SOL_WG]), v = __uint_as_float(mine[(SOL_MAIL_AT + 5) * SOL_WG]);
-      if (SOL_REF_KIND(ref) != SOL_REF_NONE && better(tt, dfs, t.h)) { t.h.t = tt; t.h.ref = ref; t.h.dfs = dfs; t.h.u = u; t.h.v = v; }
-      t.cur = 0u;
-      if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
-    }
-  }
-  // ---- hand-out: the k-th waiting lane takes the top stack entry of the k-th lane that has one to give
-  if ((turn & ((1u << SOL_DONATE_EVERY) - 1u)) != 0u) return;
-  const bool idle = t.cur == REF_DONE;
-  const unsigned long long idle_m = sol_ballot(idle);
-  if ((int)__popcll(idle_m) < SOL_DONATE_MIN) return;
-  const bool giver = t.cur == 0u && t.sp - t.sp_base >= 2;
-  const unsigned long long giver_m = sol_ballot(giver);
-  if (giver_m == 0ull) return;
-  const uint32_t n_pairs = min((uint32_t)__popcll(idle_m), (uint32_t)__popcll(giver_m));
-  const uint32_t rank_i = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-  const uint32_t rank_g = __builtin_amdgcn_mbcnt_hi((uint32_t)(giver_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)giver_m, 0u));
-  const bool gives = giver && rank_g < n_pairs, takes = idle && rank_i < n_pairs;
-  if (gives) {
-    mine[SOL_MAIL_AT * SOL_WG] = 0u;
-#if SOL_DONATE_BOTTOM  // the OLDEST entry: the far siblings of a shallow node - a large sub-tree, but the one a near hit would have culled
-    pair[rank_g] = lane | ((uint32_t)(t.sp_base + 2) << 8);
-    t.sp_base += 2;
-#else                  // the newest entry: what the donor would have searched next
-    pair[rank_g] = lane | ((uint32_t)t.sp << 8);
-    t.sp -= 2;  // (the entry stays where it is until the helper has read it: nothing is pushed before the next step)
-#endif
-    t.cur = CUR_LENT;
-  }
-  const uint32_t e = takes ? pair[rank_i] : lane;
-  const uint32_t from = e & 63u, from4 = from << 2;
-  // (every lane executes the gathers: a bpermute reads registers of enabled lanes only)
-  const uint32_t ox = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.o.x)), oy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.o.y));
-  const uint32_t oz = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.o.z)), dx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.d.x));
-  const uint32_t dy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.d.y)), dz = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.d.z));
-  const uint32_t ix = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.inv.x)), iy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.inv.y));
-  const uint32_t iz = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.inv.z)), bt = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)__float_as_uint(t.h.t));
-  const uint32_t oc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from4, (int)t.oct);
-  if (takes) {
-    mine[(SOL_PARK_AT + 0) * SOL_WG] = __float_as_uint(t.o.x); mine[(SOL_PARK_AT + 1) * SOL_WG] = __float_as_uint(t.o.y);
-    mine[(SOL_PARK_AT + 2) * SOL_WG] = __float_as_uint(t.o.z); mine[(SOL_PARK_AT + 3) * SOL_WG] = __float_as_uint(t.d.x);
-    mine[(SOL_PARK_AT + 4) * SOL_WG] = __float_as_uint(t.d.y); mine[(SOL_PARK_AT + 5) * SOL_WG] = __float_as_uint(t.d.z);
-    mine[(SOL_PARK_AT + 6) * SOL_WG] = __float_as_uint(t.h.t); mine[(SOL_PARK_AT + 7) * SOL_WG] = t.h.ref;
-    mine[(SOL_PARK_AT + 8) * SOL_WG] = __float_as_uint(t.h.u); mine[(SOL_PARK_AT + 9) * SOL_WG] = __float_as_uint(t.h.v);
-    volatile lds_u32* const col = mine - lane + from;
-    const uint32_t at = (e >> 8) - 2u;
-    t.g0 = col[at * SOL_WG];
-    t.g1 = col[(at + 1u) * SOL_WG];
-    t.pg = 0u;
-    t.sp = t.sp_base = 0;
-    t.o = mk3(__uint_as_float(ox), __uint_as_float(oy), __uint_as_float(oz));
-    t.d = mk3(__uint_as_float(dx), __uint_as_float(dy), __uint_as_float(dz));
-    t.inv = mk3(__uint_as_float(ix), __uint_as_float(iy), __uint_as_float(iz));
-    t.oct = oc;
-    t.h.t = __uint_as_float(bt);
-    t.h.ref = SOL_MAKE_REF(SOL_REF_NONE, 0);
-    t.h.dfs = 0u;
-    t.cur = CUR_HELP | from;
-  }
-}
-#endif  // SOL_DONATE
-
-// One step of a 7-wide world search for a whole WAVE (every lane of the wave calls it; `act`: the lane has a running search) - the
-// product kernel's form of trav_step: the same two parts, but the votes on the step's shape (does any lane hold primitives? are
-// they postponed?) are taken by the whole wave once instead of inside the divergent region of the searching lanes
-// (MI355X, 64 spp, ms: C3 69.57 -> 68.85, C2 44.0 -> 43.45, C1 10.37 -> 10.30; profiles/r03_coop_triangles_ab.txt).
-//
-// -DSOL_COOP_TRIANGLES=1 (an A/B build; MEASURED SLOWER, kept as the record of the experiment): the primitive part COOPERATIVELY.
-// A lane with pending primitives tests one of them per step and the primitive part runs with a quarter of the wave's lanes
-// (C3: 16.0 of 64), a fifth of all vector instructions of a launch at that occupancy. In the cooperative form all
-// pending TRIANGLE tests of the wave - every hit leaf slot of every lane's primitive group - are dealt out over all 64 lanes,
-// finished and node-only lanes included: the owners list their tests in a 64-entry LDS queue (exclusive prefix of their counts by
-// three ballots), the r-th enabled lane takes entry r, gathers the owner's ray and best t (ds_bpermute: the LDS crossbar, no
-// memory), tests the triangle, and the owners collect the results by the (t, dfs) rule of `better` - a total order, so neither
-// who tests nor in which order changes the hit (frames bit-identical). It loses: listing and collecting are loops over the
-// largest primitive group of the wave (~12 + ~25 vector instructions per turn) around a 60-instruction test, and a primitive part
-// deals out 20 - 30 tests, not 64: C3 69.6 -> 74.1 ms with the postponing rule at 8 lanes, 72.0 at 16, 75.0 at 24, 80.5 at 4.
+// One step of a 7-wide world search for a whole WAVE (every lane of the wave that is still in the kernel calls it; `act`: the lane
+// has a running search). Part 1 - a lane without pending primitives takes the nearest child of its node group (wide_visit): a new
+// node group and a new primitive group. Part 2 - a lane with pending primitives tests ONE of them. A lane so advances by up to two
+// visits per step, while a wave whose lanes are spread over nodes and primitives pays for both parts anyway. The votes on the
+// step's shape (does any lane hold primitives? are they postponed?) are taken by the whole wave once, not inside the divergent
+// region of the searching lanes (MI355X, 64 spp, ms: C3 69.57 -> 68.85, C2 44.0 -> 43.45, C1 10.37 -> 10.30).
 template <bool COUNT, bool MEDIUM>
-DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, volatile lds_u32* queue, const Rng& rng, uint32_t depth,
-                        Counters& cnt) {
+DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
   if (act) {
     phase_tick<COUNT>(cnt, 0);
-#if SOL_DONATE
-    // (a lane whose own search is exhausted while a group of it is out with a helper stays in the loop without work)
-    if ((t.pg >> 24) == 0u && ((t.g0 >> 24) != 0u || t.sp != t.sp_base)) wide_visit<COUNT>(t, st, cnt);
-#else
     if ((t.pg >> 24) == 0u) wide_visit<COUNT>(t, st, cnt);
-#endif
   }
   const bool has_prim = act && (t.pg >> 24) != 0u;
   const bool has_inner = act && !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);
-  if (act && !has_prim && !has_inner) trav_out_of_work(t);
+  if (act && !has_prim && !has_inner) t.cur = REF_DONE;
   const unsigned long long prim_m = sol_ballot(has_prim);
   if (prim_m == 0ull) return;
 #if SOL_PRIM_MIN > 1
   // Postponed primitive tests: while fewer than SOL_PRIM_MIN lanes hold primitives and some lane has an inner node to visit next
-  // turn, the holders wait (a later primitive part then has more tests to deal out)
+  // turn, the holders wait (a later primitive part then runs with more lanes enabled). Results do not depend on the order of the tests.
   if (sol_ballot(has_inner) != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) return;
 #endif
-  const uint32_t lkind = t.g1 >> 29;
-  if (has_prim && (SOL_COOP_TRIANGLES == 0 || lkind != SOL_LEAF_TRIANGLES)) {  // part 2 of trav_step: ONE of the lane's own primitives
+  const uint32_t lkind = t.g1 >> 29;  // (no group was popped since this node's test: a lane with pending primitives skips part 1)
+  if (has_prim) {
     const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
     t.pg &= ~(1u << (24u + slot));
     uint32_t idx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(t.g1, 22u, slot));  // lmask bits below `slot`
-    if (lkind == SOL_LEAF_TRIANGLES) {  // (straight to their test, not through prim_test's chain: nine vector instructions less)
+    // Triangle leaves go straight to their test: through prim_test's chain (leaf kind -> reference kind -> compare tree) every
+    // test had nine more vector instructions in front of it (C3 74.8 -> 73.3 ms per 64 spp); the other kinds keep the chain.
+    if (lkind == SOL_LEAF_TRIANGLES) {
       triangle_prim_test<COUNT>(t, st, idx, cnt);
     } else {
       uint32_t kind = lkind == SOL_LEAF_SPHERES ? SOL_REF_SPHERE : SOL_REF_QUAD;
@@ -832,105 +527,33 @@ DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, v
       }
       prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
     }
-    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) trav_out_of_work(t);
-  }
-#if SOL_COOP_TRIANGLES
-  const bool tri_owner = has_prim && lkind == SOL_LEAF_TRIANGLES;
-  if (sol_ballot(tri_owner) == 0ull) return;
-  // ---- the wave's pending triangle tests, dealt out over all its lanes ----
-  const uint32_t lane = __lane_id();
-  const uint32_t pend = tri_owner ? (t.pg >> 24) : 0u;
-  const uint32_t n = (uint32_t)__popc(pend);
-  const unsigned long long m0 = sol_ballot((n & 1u) != 0u), m1 = sol_ballot((n & 2u) != 0u), m2 = sol_ballot((n & 4u) != 0u);
-  const uint32_t first = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u)) +
-                         2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)) +
-                         4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
-  const uint32_t total = (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1) + 4u * (uint32_t)__popcll(m2);
-  // Entry r of the queue goes to the r-th ENABLED lane of the wave (at the end of a launch lanes without work have left the kernel:
-  // nothing may be dealt to them, and a bpermute reads registers of enabled lanes only)
-  const unsigned long long live = sol_ballot(true);
-  const uint32_t n_live = (uint32_t)__popcll(live);
-  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-  // owners list their tests (triangle index | owner lane << 24) at queue[first ..]; what does not fit stays pending
-  uint32_t listed = 0u;  // the slots this lane got into the queue
-  {
-    uint32_t rest = pend, pos = first;
-    while (rest != 0u && pos < n_live) {
-      const uint32_t slot = (uint32_t)__builtin_ctz(rest);
-      rest &= rest - 1u;
-      listed |= 1u << slot;
-      queue[pos++] = ((t.pg & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(t.g1, 22u, slot))) | (lane << 24);
-    }
-  }
-  const uint32_t n_tests = min(total, n_live);
-  const bool tester = rank < n_tests;
-  const uint32_t e = tester ? queue[rank] : (lane << 24);
-  if (tester) queue[rank] = lane;  // (its own entry, read above: where the owner finds the result)
-  const uint32_t owner4 = (e >> 24) << 2;  // byte address of the owner lane for ds_bpermute (all lanes execute the gathers: a
-                                           // bpermute reads registers of ENABLED lanes only)
-  f3 o, d;
-  o.x = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.o.x)));
-  o.y = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.o.y)));
-  o.z = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.o.z)));
-  d.x = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.d.x)));
-  d.y = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.d.y)));
-  d.z = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.d.z)));
-  const float tmax = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)owner4, (int)__float_as_uint(t.h.t)));
-  float rt = __builtin_huge_valf(), ru = 0.0f, rv = 0.0f;  // this lane's result: t = +inf when the triangle is not hit
-  uint32_t rdfs = 0u;
-  const uint32_t ridx = e & SOL_WIDE_MAX_INDEX;
-  if (tester) {
-    const float4* tp = reinterpret_cast<const float4*>(st.tris + ridx);
-#if SOL_FETCH_PRIO >= 10
-    __builtin_amdgcn_s_setprio(SOL_FETCH_PRIO / 10);
-#endif
-    const float4 p0 = ldg_f4(tp), p1 = ldg_f4(tp + 1), p2 = ldg_f4(tp + 2);
-#if SOL_FETCH_PRIO >= 10
-    asm volatile("s_setprio %0" ::"n"(SOL_LOOP_PRIO) : "memory");
-#endif
-    DTri T;
-    T.v0x = p0.x; T.v0y = p0.y; T.v0z = p0.z; T.e1x = p0.w; T.e1y = p1.x; T.e1z = p1.y; T.e2x = p1.z; T.e2y = p1.w; T.e2z = p2.x;
-    rdfs = __float_as_uint(p2.y);
-    if (COUNT) cnt.triangle_tests++;
-    float tt, u, v;
-    if (tri_test(T, o, d, RAY_MIN_F, tmax, tt, u, v)) { rt = tt; ru = u; rv = v; }  // (a world search starts at RAY_MIN_F: trav_begin)
-  }
-  // owners collect their results, in queue order. The loop's trip count is wave-uniform and every lane executes the gathers.
-  {
-    uint32_t rest = listed, pos = first;
-    while (sol_ballot(rest != 0u) != 0ull) {
-      const uint32_t src4 = (rest != 0u ? queue[pos] : lane) << 2;
-      const float tt = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)src4, (int)__float_as_uint(rt)));
-      const float u = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)src4, (int)__float_as_uint(ru)));
-      const float v = __uint_as_float(__builtin_amdgcn_ds_bpermute((int)src4, (int)__float_as_uint(rv)));
-      const uint32_t dfs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)rdfs);
-      const uint32_t idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)ridx);
-      if (rest != 0u) {
-        rest &= rest - 1u;
-        pos++;
-        if (tt < __builtin_huge_valf() && better(tt, dfs, t.h)) {
-          t.h.t = tt; t.h.ref = SOL_MAKE_REF(SOL_REF_TRIANGLE, idx); t.h.dfs = dfs; t.h.u = u; t.h.v = v;
-        }
-      }
-    }
-  }
-  if (tri_owner) {
-    t.pg &= ~(listed << 24);
     if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
   }
-#else
-  (void)queue;
-#endif
 }
 
-// Run-to-completion form.
-template <bool COUNT, bool MEDIUM, bool BINARY>
-DEV void closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, uint32_t root, float bxmin, float bxmax,
-                     float bymin, float bymax, float bzmin, float bzmax, Hit& h, const Stack& st, int sp_base, const Rng& rng,
+// The same step for callers outside the product kernel's loop (the diagnostic path kernel, the A/B wavefront kernels): the lanes
+// that call it are the wave as far as its votes are concerned.
+template <bool COUNT, bool MEDIUM>
+DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
+  trav_step_wave<COUNT, MEDIUM>(S, t, true, st, rng, depth, cnt);
+}
+
+// Run-to-completion forms: the world (7-wide tree), and a medium boundary (2-wide tree, its own box tested first: Bvh::hit).
+template <bool COUNT, bool MEDIUM>
+DEV void closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, Hit& h, const Stack& st, int sp_base, const Rng& rng,
                      uint32_t depth, Counters& cnt) {
   Trav t;
-  trav_begin<!BINARY>(t, o, d, tmin, tmax, root, bxmin, bxmax, bymin, bymax, bzmin, bzmax, sp_base);
-  while (t.cur != REF_DONE) trav_step<COUNT, MEDIUM, BINARY>(S, t, st, rng, depth, cnt);
+  trav_begin<true>(t, o, d, tmin, tmax, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, sp_base);
+  while (t.cur != REF_DONE) trav_step<COUNT, MEDIUM>(S, t, st, rng, depth, cnt);
+  h = t.h;
+}
+template <bool COUNT>
+DEV void boundary_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, uint32_t root, float bxmin, float bxmax, float bymin,
+                      float bymax, float bzmin, float bzmax, Hit& h, const Stack& st, int sp_base, const Rng& rng, uint32_t depth,
+                      Counters& cnt) {
+  Trav t;
+  trav_begin<false>(t, o, d, tmin, tmax, root, bxmin, bxmax, bymin, bymax, bzmin, bzmax, sp_base);
+  while (t.cur != REF_DONE) boundary_step<COUNT>(S, t, st, rng, depth, cnt);
   h = t.h;
 }
 
@@ -943,11 +566,9 @@ DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, f
   const DMedium M = ldg_rec(S.mediums + midx);
   const float inf = __builtin_huge_valf();
   Hit h1, h2;
-  closest_hit<COUNT, false, true>(S, o, d, -inf, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax, h1, st, sp,
-                            rng, depth, cnt);
+  boundary_hit<COUNT>(S, o, d, -inf, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax, h1, st, sp, rng, depth, cnt);
   if (SOL_REF_KIND(h1.ref) == SOL_REF_NONE) return false;
-  closest_hit<COUNT, false, true>(S, o, d, h1.t + 0.0001f, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax,
-                            h2, st, sp, rng, depth, cnt);
+  boundary_hit<COUNT>(S, o, d, h1.t + 0.0001f, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax, h2, st, sp, rng, depth, cnt);
   if (SOL_REF_KIND(h2.ref) == SOL_REF_NONE) return false;
   float t1 = fmaxf(h1.t, tmin);
   float t2 = fminf(h2.t, tmax);

@@ -1,7 +1,7 @@
 // sol_tree.h -- host-side builders of the device's trees (included by sol_api.cpp only; nothing here runs per sample).
 //
 //   TreeBuilder  the reference-shaped binary tree (SolBvhNode, own box per node) -> DNode (child boxes in the parent): walked by
-//                the boundary searches of ConstantMedium and by the -DSOL_WORLD_BINARY=true A/B build;
+//                the boundary searches of ConstantMedium;
 //   SahBuilder   a binned surface-area-heuristic rebuild of the WORLD's binary tree over the same primitives;
 //   WideBuilder  collapse of a binary tree into 7-wide nodes with 8-bit quantised child boxes, in explicit form (XWide: one
 //                reference per child);
@@ -118,10 +118,6 @@ struct TreeBuilder {
     Box lb, rb;
     if (!resolve(n.left, depth + 1, lr, lb) || !resolve(n.right, depth + 1, rr, rb)) return false;
     on_path[i] = 0;
-#ifdef SOL_NO_LEAF_BOX  // debug variant: no extra per-primitive boxes in two-leaf nodes (the reference tests none)
-    if (lk != SOL_REF_NONE && lk != SOL_REF_NODE) lb = Box{{-F_INF, F_INF, -F_INF, F_INF, -F_INF, F_INF}};
-    if (rk != SOL_REF_NONE && rk != SOL_REF_NODE) rb = Box{{-F_INF, F_INF, -F_INF, F_INF, -F_INF, F_INF}};
-#endif
     DNode& dn = nodes[di];
     dn.lxmin = lb.v[0]; dn.lxmax = lb.v[1]; dn.lymin = lb.v[2]; dn.lymax = lb.v[3]; dn.lzmin = lb.v[4]; dn.lzmax = lb.v[5];
     dn.rxmin = rb.v[0]; dn.rxmax = rb.v[1]; dn.rymin = rb.v[2]; dn.rymax = rb.v[3]; dn.rzmin = rb.v[4]; dn.rzmax = rb.v[5];

@@ -20,12 +20,6 @@
                             // MI355X, 1080p x 128 spp, C3 / C2 ms: 1: 199.8 / 128.4, 4: 196.6 / 126.5, 8: 193.1 / 122.5,
                             // 12: 193.0 / 122.6, 16: 199.1 / 129.7, 24: 215.7 / 148.0
 #endif
-#ifndef SOL_CLAMP_SLABS
-#define SOL_CLAMP_SLABS 1         // node test in units of the cull distance with clamped plane FMAs (sol_trace.h); implies the half-plane form
-#endif
-#ifndef SOL_HALF_PLANES
-#define SOL_HALF_PLANES 1
-#endif
 #ifndef SOL_FETCH_PRIO
 #define SOL_FETCH_PRIO 33        // s_setprio around the loads of a search step (units: node fetch, tens: triangle fetch; 0 off): the wave
                                  // about to fetch issues its addresses and loads ahead of the waves in their arithmetic
@@ -35,25 +29,6 @@
                                  // dependent fetches, shading is throughput work. MI355X, 64 spp, ms with (loop, fetch) = (0, 0) /
                                  // (0, 1) / (1, 3): C3 70.6 / 70.0 / 69.4, C2 44.6 / 44.3 / 43.8, C1 10.56 / - / 10.39; the service block at 1 or 2 as
                                  // well: C3 70.3 (slower)
-#endif
-#ifndef SOL_LEAF_KIND_DISPATCH
-#define SOL_LEAF_KIND_DISPATCH 1  // primitive part of trav_step: 0 every kind through prim_test's chain, 1 triangle leaves direct
-#endif
-#ifndef SOL_WAVE_STEP
-#define SOL_WAVE_STEP 1           // search loop of the product kernel: 1 = trav_step_wave (the whole wave votes on the shape of a step), 0 =
-                                  // trav_step under the mask of the searching lanes (round 2)
-#endif
-#ifndef SOL_PARK_PATH
-#define SOL_PARK_PATH 0           // product kernel: the path's throughput registers (A, C) live in LDS during a search (sol_render.hip)
-#endif
-#ifndef SOL_DONATE
-#define SOL_DONATE 0              // 1: A/B build - intra-wave donation of pending node groups (sol_trace.h, trav_donate)
-#endif
-#ifndef SOL_DONATE_BOTTOM
-#define SOL_DONATE_BOTTOM 0
-#endif
-#ifndef SOL_COOP_TRIANGLES
-#define SOL_COOP_TRIANGLES 0      // 1: A/B build - the wave's pending triangle tests dealt out over all its lanes (trav_step_wave; measured slower)
 #endif
 #define SOL_CHUNK 16        // samples per work item; fixed so that summation order never depends on the partition
 #define SOL_TILE 8          // 8x8-pixel blocks = one wave's worth of adjacent work items
@@ -86,9 +61,6 @@ static_assert(sizeof(DNode) == 64, "DNode");
 //     kind 1: the triangle array, 2: the sphere array, 3: the quad array (the arrays are permuted at upload so that the
 //     primitives of a node are consecutive), 0: DevScene::leaf_refs (full references; nodes with mixed kinds or a medium).
 #define SOL_REF_WIDE 6u  // device-only reference kind
-#ifndef SOL_WORLD_BINARY
-#define SOL_WORLD_BINARY false  // -DSOL_WORLD_BINARY=true: A/B variant that walks the 2-wide tree for the world as well
-#endif
 #define SOL_WIDE_CHILDREN 7
 #define SOL_WIDE_MAX_INDEX 0x00FFFFFFu  // 24-bit base indices
 struct __attribute__((aligned(64))) DWide {
@@ -244,7 +216,6 @@ struct RenderParams {
   uint32_t n_coarse;
   uint32_t fine_count;       // samples of the last chunk (1 .. 16): fine items with sub >= fine_count do not exist
   uint32_t stage_at;
-  uint32_t donate;           // 1: finished lanes adopt node groups of searching lanes of their wave (sol_trace.h, trav_donate; -DSOL_DONATE builds)
 };
 
 struct DevCounters {

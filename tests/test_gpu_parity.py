@@ -104,27 +104,6 @@ def test_wavefront_ab_kernels_are_bit_identical():
             assert e.value.code == _abi.SOL_EINVAL and "SOL_AB_KERNELS" in str(e.value)
 
 
-@pytest.mark.parametrize("name", ["donate", "coop_triangles", "round2_step"])
-def test_rejected_experiments_keep_every_frame(name):
-    """intra-wave donation of pending node groups (-DSOL_DONATE=1) and cooperative triangle tests
-    (-DSOL_COOP_TRIANGLES=1) were built, measured and rejected because they are SLOWER (profiles/r03_donation_ab.txt,
-    r03_coop_triangles_ab.txt) - not because they change anything: who searches a sub-tree or tests a triangle, and with which cull
-    distance, does not change the closest hit (bvh.rs:165-180 result contract). `round2_step` is the search step and node
-    test of round 2 (A/B base of profiles/r03_clamp_slabs_ab.txt). Each variant's frames must equal the product library's bit for bit."""
-    import json
-    import subprocess
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-    import frame_crc
-    want = frame_crc.crcs([1])
-    exp_dir = os.path.join(os.path.dirname(_abi.BUILD_DIR), "_build_exp", name)
-    assert os.path.exists(os.path.join(exp_dir, "libsolstrale_hip.so")), "the experiment libraries are missing: __graft_entry__.build() makes them"
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "frame_crc.py"), "1"],
-                       env=dict(os.environ, SOLSTRALE_BUILD_DIR=exp_dir), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert json.loads(r.stdout.strip().splitlines()[-1]) == want
-
-
 def test_device_built_tree_renders_the_same_frames():
     """SolCreateOptions.world_tree = SOL_TREE_DEVICE: the world tree built by the GPU kernels of sol_build.hip instead of the
     host builders. Closest hits do not depend on the tree, so the frames must be bit-identical (reference rule the device

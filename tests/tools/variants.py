@@ -22,14 +22,26 @@ def build(specs):
 
 
 def run(names, spp, scenes):
+    """Exit code != 0 when a requested variant is missing or its run failed: a sweep must not silently time nothing."""
+    failed = []
     for name in names:
         env = dict(os.environ)
         if name != "default":
             env["SOLSTRALE_BUILD_DIR"] = os.path.join(VAR, name)
+            if not os.path.exists(os.path.join(VAR, name, "libsolstrale_hip.so")):
+                print(f"== {name}\nMISSING: {os.path.join(VAR, name)}/libsolstrale_hip.so (build it first: variants.py build {name}=..)", flush=True)
+                failed.append(name)
+                continue
         print(f"== {name}", flush=True)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "perf_quick.py")] + scenes + ["--spp", str(spp)],
-                           env=env, capture_output=True, text=True, timeout=600)
-        print(r.stdout.strip() or r.stderr[-800:], flush=True)
+                           env=env, capture_output=True, text=True, timeout=900)
+        print(r.stdout.strip(), flush=True)
+        if r.returncode != 0:
+            print(f"FAILED (rc {r.returncode}): {r.stderr[-800:]}", flush=True)
+            failed.append(name)
+    if failed:
+        print(f"variants that did not run: {' '.join(failed)}", flush=True)
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":
@@ -42,4 +54,4 @@ if __name__ == "__main__":
             i = a.index("--spp"); spp = int(a[i + 1]); del a[i:i + 2]
         if "--scenes" in a:
             i = a.index("--scenes"); scenes = a[i + 1].split(); del a[i:i + 2]
-        run(a, spp, scenes)
+        sys.exit(run(a, spp, scenes))
