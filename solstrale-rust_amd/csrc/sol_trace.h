@@ -212,6 +212,21 @@ DEV bool better(float t, uint32_t dfs, const Hit& h) {
 //   prim group  pg = base_prim | hit leaf slots << 24  (leaf kind and lmask: g1, the same node's meta word) - the hit primitives of
 //               the node visited last; they are tested before the search descends further.
 // `cur` is only the status of such a search: REF_DONE when it is over, 0 while it runs.
+//
+// ConstantMedium::hit (constant_medium.rs:35-79) is two closest-hit searches of the medium's boundary. A world search that reaches
+// a medium keeps them as a SUB-STATE (MedSearch, kernels built with MEDIUM only) and advances it one boundary step per turn of the
+// wave's search loop, beside the other lanes' world steps, instead of running both searches to completion inside one primitive
+// test while the rest of the wave idles (round 3: lane utilisation 0.22 on the reference's own profiling workload).
+struct MedSearch {
+  uint32_t phase;  // 0: no medium test running; 1 / 2: the first / second boundary search
+  uint32_t midx;   // the medium
+  uint32_t cur;    // boundary search: the reference being visited (REF_DONE: over)
+  int sp;          // its stack pointer; its entries lie above the world search's (base = Trav::sp, which rests meanwhile)
+  float tmin;      // lower end of its interval: -inf, then t1 + 0.0001
+  float t, t1;     // its best hit so far; the first search's hit
+  uint32_t ref, dfs;
+  f3 inv;          // 1 / d as Ray::new makes it (the world search's copy is clamped for the 7-wide node test)
+};
 struct Trav {
   f3 o, d, inv;
   float tmin;
@@ -219,6 +234,7 @@ struct Trav {
   int sp, sp_base;
   uint32_t g0, g1, pg, oct;  // (7-wide searches only; oct = the ray's octant, sign bits of the direction as x<<2 | y<<1 | z)
   Hit h;
+  MedSearch m;               // (MEDIUM kernels only; dead otherwise)
 };
 
 // Starts a search of `root` over [tmin, tmax]; (bxmin..bzmax) is root's own box, tested first when root is a node
@@ -238,6 +254,7 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
   t.g0 = root | (1u << 24);
   t.g1 = 0u;
   t.pg = 0u;
+  t.m.phase = 0u;
   t.oct = (__builtin_signbitf(t.inv.x) ? 4u : 0u) | (__builtin_signbitf(t.inv.y) ? 2u : 0u) | (__builtin_signbitf(t.inv.z) ? 1u : 0u);
   // A ray with a NaN in its origin or direction cannot hit anything: every primitive test ends in a comparison with NaN,
   // which is false (the reference returns None the same way, after visiting every box - Aabb::hit ignores NaN). Such rays
@@ -253,10 +270,6 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
   // direction component becomes the containment test it should be instead of NaN); clamped here, once per ray, not once per node
   if (WIDE) t.inv = mk3(__builtin_amdgcn_fmed3f(t.inv.x, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(t.inv.y, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(t.inv.z, -1e30f, 1e30f));
 }
-
-template <bool COUNT>
-DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, float tmax, float& t_out, const Stack& st,
-                     int sp, const Rng& rng, uint32_t depth, Counters& cnt);
 
 // Decodes child `i` (compile-time) of a wide node and tests it; sets bit i of `hits` when the child must be visited.
 // The slab test runs in t-space: plane q of an axis is crossed at  t = A + q * B  with  A = (origin - o) * inv,
@@ -389,22 +402,15 @@ DEV void quad_prim_test(const DevScene& S, Trav& t, uint32_t idx, Counters& cnt)
     t.h.t = tt; t.h.ref = SOL_MAKE_REF(SOL_REF_QUAD, idx); t.h.dfs = Q.dfs; t.h.u = u; t.h.v = v;
   }
 }
-template <bool COUNT, bool MEDIUM>
-DEV void prim_test(const DevScene& S, Trav& t, const Stack& st, uint32_t kind, uint32_t idx, const Rng& rng, uint32_t depth,
-                   Counters& cnt) {
-  const uint32_t ref = SOL_MAKE_REF(kind, idx);
+// (a constant medium is not tested here: a world search starts its boundary searches as a sub-state, medium_begin)
+template <bool COUNT>
+DEV void prim_test(const DevScene& S, Trav& t, const Stack& st, uint32_t kind, uint32_t idx, Counters& cnt) {
   if (kind == SOL_REF_TRIANGLE) {
     triangle_prim_test<COUNT>(t, st, idx, cnt);
   } else if (kind == SOL_REF_SPHERE) {
     sphere_prim_test<COUNT>(S, t, idx, cnt);
   } else if (kind == SOL_REF_QUAD) {
     quad_prim_test<COUNT>(S, t, idx, cnt);
-  } else if (MEDIUM && kind == SOL_REF_MEDIUM) {
-    float tt;
-    const uint32_t dfs = ldg_u32(&S.mediums[idx].dfs);
-    if (medium_test<COUNT>(S, idx, t.o, t.d, t.tmin, t.h.t, tt, st, t.sp, rng, depth, cnt) && better(tt, dfs, t.h)) {
-      t.h.t = tt; t.h.ref = ref; t.h.dfs = dfs;
-    }
   }
 }
 
@@ -443,8 +449,7 @@ DEV void wide_visit(Trav& t, const Stack& st, Counters& cnt) {
 // One step of a search of the 2-wide DNode tree (the boundary of a constant medium, whose interval includes negative t): visits
 // the node or primitive t.cur, then moves to the next reference (near child, or popped from the stack).
 template <bool COUNT>
-DEV void boundary_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
-  phase_tick<COUNT>(cnt, 0);
+DEV void boundary_step(const DevScene& S, Trav& t, const Stack& st, Counters& cnt) {
   uint32_t cur = t.cur;
   uint32_t kind = SOL_REF_KIND(cur);
   if (kind == SOL_REF_NODE) {
@@ -483,8 +488,65 @@ DEV void boundary_step(const DevScene& S, Trav& t, const Stack& st, const Rng& r
     kind = SOL_REF_KIND(cur);
   }
   if (cur == REF_DONE || kind == SOL_REF_NODE) { t.cur = cur; return; }
-  prim_test<COUNT, false>(S, t, st, kind, SOL_REF_INDEX(cur), rng, depth, cnt);
+  prim_test<COUNT>(S, t, st, kind, SOL_REF_INDEX(cur), cnt);
   t.cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
+}
+
+// ---- ConstantMedium::hit (src/hittable/constant_medium.rs:35-79) as a sub-state of the world search ----
+// Its draws come from the sub-stream 0x40000000 + (depth<<20 | medium<<8) + i of the path's generator (DESIGN.md "RNG"), so the
+// outcome does not depend on when the tree search reaches the medium, nor on how its steps interleave with other lanes'.
+// Starts boundary search `phase` (1: over (-inf, inf); 2: over [t1 + 0.0001, inf), constant_medium.rs:39-49).
+DEV void medium_search_begin(const DevScene& S, Trav& t, uint32_t phase) {
+  const DMedium M = ldg_rec(S.mediums + t.m.midx);
+  const float inf = __builtin_huge_valf();
+  Trav b;
+  trav_begin<false>(b, t.o, t.d, phase == 1u ? -inf : t.m.t1 + 0.0001f, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax, t.sp);
+  t.m.phase = phase;
+  t.m.cur = b.cur; t.m.sp = b.sp; t.m.tmin = b.tmin; t.m.t = b.h.t; t.m.ref = b.h.ref; t.m.dfs = b.h.dfs; t.m.inv = b.inv;
+}
+// The world search of `t` has reached medium `midx` (a primitive of its tree): the first boundary search starts.
+DEV void medium_begin(const DevScene& S, Trav& t, uint32_t midx) {
+  t.m.midx = midx;
+  medium_search_begin(S, t, 1u);
+}
+// One turn of a lane inside a medium test: one step of the running boundary search; when that search is over, the next one
+// starts or the medium's hit - if there is one - is offered to the world search.
+template <bool COUNT>
+DEV void medium_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
+  if (t.m.cur != REF_DONE) {
+    Trav b;
+    b.o = t.o; b.d = t.d; b.inv = t.m.inv; b.tmin = t.m.tmin; b.cur = t.m.cur; b.sp = t.m.sp; b.sp_base = t.sp;
+    b.h.t = t.m.t; b.h.ref = t.m.ref; b.h.dfs = t.m.dfs; b.h.u = b.h.v = 0.0f;
+    boundary_step<COUNT>(S, b, st, cnt);
+    t.m.cur = b.cur; t.m.sp = b.sp; t.m.t = b.h.t; t.m.ref = b.h.ref; t.m.dfs = b.h.dfs;
+  }
+  if (t.m.cur != REF_DONE) return;
+  const bool found = SOL_REF_KIND(t.m.ref) != SOL_REF_NONE;
+  if (found && t.m.phase == 1u) {  // rec1 (constant_medium.rs:39-41): on to rec2
+    t.m.t1 = t.m.t;
+    medium_search_begin(S, t, 2u);
+    return;
+  }
+  if (found) {  // rec2 (constant_medium.rs:43-49): the segment inside the boundary, the free path (:51-66)
+    const uint32_t midx = t.m.midx;
+    float t1 = fmaxf(t.m.t1, t.tmin);
+    const float t2 = fminf(t.m.t, t.h.t);  // (the world search rested meanwhile: its best t is the one the test began with)
+    if (t1 < t2) {
+      t1 = fmaxf(t1, 0.0f);
+      const float r_length = len3(t.d);
+      const float distance_inside = (t2 - t1) * r_length;
+      const uint32_t c = 0x40000000u + (((depth & 0x3FFu) << 20) | ((midx & 0xFFFu) << 8));
+      const float nid = __uint_as_float(ldg_u32(reinterpret_cast<const uint32_t*>(&S.mediums[midx].nid)));
+      const float hit_distance = nid * log_r(u32_to_unit(rng_bits(rng, c)));
+      if (!(hit_distance > distance_inside)) {
+        const float tt = t1 + hit_distance / r_length;
+        const uint32_t dfs = ldg_u32(&S.mediums[midx].dfs);
+        if (better(tt, dfs, t.h)) { t.h.t = tt; t.h.ref = SOL_MAKE_REF(SOL_REF_MEDIUM, midx); t.h.dfs = dfs; }
+      }
+    }
+  }
+  t.m.phase = 0u;  // the world search goes on
+  if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
 }
 
 // One step of a 7-wide world search for a whole WAVE (every lane of the wave that is still in the kernel calls it; `act`: the lane
@@ -495,22 +557,33 @@ DEV void boundary_step(const DevScene& S, Trav& t, const Stack& st, const Rng& r
 // region of the searching lanes (MI355X, 64 spp, ms: C3 69.57 -> 68.85, C2 44.0 -> 43.45, C1 10.37 -> 10.30).
 template <bool COUNT, bool MEDIUM>
 DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
+  // (MEDIUM) a lane inside a medium test rests its world search: no node visit, no primitive of its group, until the test is over
+  const bool world = !MEDIUM || t.m.phase == 0u;
   if (act) {
     phase_tick<COUNT>(cnt, 0);
-    if ((t.pg >> 24) == 0u) wide_visit<COUNT>(t, st, cnt);
+    if (world && (t.pg >> 24) == 0u) wide_visit<COUNT>(t, st, cnt);
   }
-  const bool has_prim = act && (t.pg >> 24) != 0u;
-  const bool has_inner = act && !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);
-  if (act && !has_prim && !has_inner) t.cur = REF_DONE;
+  const bool has_prim = act && world && (t.pg >> 24) != 0u;
+  const bool has_inner = act && world && !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);
+  if (act && world && !has_prim && !has_inner) t.cur = REF_DONE;
   const unsigned long long prim_m = sol_ballot(has_prim);
-  if (prim_m == 0ull) return;
+  bool prims = true;  // does the primitive part run in this turn?
+  if (!MEDIUM) {
+    if (prim_m == 0ull) return;
 #if SOL_PRIM_MIN > 1
-  // Postponed primitive tests: while fewer than SOL_PRIM_MIN lanes hold primitives and some lane has an inner node to visit next
-  // turn, the holders wait (a later primitive part then runs with more lanes enabled). Results do not depend on the order of the tests.
-  if (sol_ballot(has_inner) != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) return;
+    // Postponed primitive tests: while fewer than SOL_PRIM_MIN lanes hold primitives and some lane has an inner node to visit
+    // next turn, the holders wait (a later primitive part then runs with more lanes enabled). Results do not depend on the order
+    // of the tests.
+    if (sol_ballot(has_inner) != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) return;
 #endif
+  } else {  // (the same votes, but part 3 below still has to run)
+    prims = prim_m != 0ull;
+#if SOL_PRIM_MIN > 1
+    if (prims && sol_ballot(has_inner) != 0ull && (int)__popcll(prim_m) < SOL_PRIM_MIN) prims = false;
+#endif
+  }
   const uint32_t lkind = t.g1 >> 29;  // (no group was popped since this node's test: a lane with pending primitives skips part 1)
-  if (has_prim) {
+  if (has_prim && prims) {
     const uint32_t slot = (uint32_t)__builtin_ctz(t.pg >> 24);
     t.pg &= ~(1u << (24u + slot));
     uint32_t idx = (t.pg & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(t.g1, 22u, slot));  // lmask bits below `slot`
@@ -525,9 +598,14 @@ DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, c
         kind = SOL_REF_KIND(r);
         idx = SOL_REF_INDEX(r);
       }
-      prim_test<COUNT, MEDIUM>(S, t, st, kind, idx, rng, depth, cnt);
+      if (MEDIUM && kind == SOL_REF_MEDIUM) medium_begin(S, t, idx);
+      else prim_test<COUNT>(S, t, st, kind, idx, cnt);
     }
-    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base) t.cur = REF_DONE;
+    if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base && !(MEDIUM && t.m.phase != 0u)) t.cur = REF_DONE;
+  }
+  if (MEDIUM) {  // part 3: one boundary step for every lane inside a medium test (those that began it in this turn included)
+    const bool in_medium = act && t.m.phase != 0u;
+    if (sol_ballot(in_medium) != 0ull && in_medium) medium_step<COUNT>(S, t, st, rng, depth, cnt);
   }
 }
 
@@ -538,7 +616,7 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
   trav_step_wave<COUNT, MEDIUM>(S, t, true, st, rng, depth, cnt);
 }
 
-// Run-to-completion forms: the world (7-wide tree), and a medium boundary (2-wide tree, its own box tested first: Bvh::hit).
+// Run-to-completion form of a world search.
 template <bool COUNT, bool MEDIUM>
 DEV void closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, Hit& h, const Stack& st, int sp_base, const Rng& rng,
                      uint32_t depth, Counters& cnt) {
@@ -546,41 +624,6 @@ DEV void closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, Hit&
   trav_begin<true>(t, o, d, tmin, tmax, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, sp_base);
   while (t.cur != REF_DONE) trav_step<COUNT, MEDIUM>(S, t, st, rng, depth, cnt);
   h = t.h;
-}
-template <bool COUNT>
-DEV void boundary_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, uint32_t root, float bxmin, float bxmax, float bymin,
-                      float bymax, float bzmin, float bzmax, Hit& h, const Stack& st, int sp_base, const Rng& rng, uint32_t depth,
-                      Counters& cnt) {
-  Trav t;
-  trav_begin<false>(t, o, d, tmin, tmax, root, bxmin, bxmax, bymin, bymax, bzmin, bzmax, sp_base);
-  while (t.cur != REF_DONE) boundary_step<COUNT>(S, t, st, rng, depth, cnt);
-  h = t.h;
-}
-
-// ConstantMedium::hit (src/hittable/constant_medium.rs:35-79). Its draws come from the sub-stream
-// 0x40000000 + (depth<<20 | medium<<8) + i of the path's generator (DESIGN.md "RNG"), so the outcome does not
-// depend on when the tree search reaches the medium.
-template <bool COUNT>
-DEV bool medium_test(const DevScene& S, uint32_t midx, f3 o, f3 d, float tmin, float tmax, float& t_out, const Stack& st,
-                     int sp, const Rng& rng, uint32_t depth, Counters& cnt) {
-  const DMedium M = ldg_rec(S.mediums + midx);
-  const float inf = __builtin_huge_valf();
-  Hit h1, h2;
-  boundary_hit<COUNT>(S, o, d, -inf, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax, h1, st, sp, rng, depth, cnt);
-  if (SOL_REF_KIND(h1.ref) == SOL_REF_NONE) return false;
-  boundary_hit<COUNT>(S, o, d, h1.t + 0.0001f, inf, M.boundary, M.bxmin, M.bxmax, M.bymin, M.bymax, M.bzmin, M.bzmax, h2, st, sp, rng, depth, cnt);
-  if (SOL_REF_KIND(h2.ref) == SOL_REF_NONE) return false;
-  float t1 = fmaxf(h1.t, tmin);
-  float t2 = fminf(h2.t, tmax);
-  if (t1 >= t2) return false;
-  t1 = fmaxf(t1, 0.0f);
-  float r_length = len3(d);
-  float distance_inside = (t2 - t1) * r_length;
-  uint32_t c = 0x40000000u + (((depth & 0x3FFu) << 20) | ((midx & 0xFFFu) << 8));
-  float hit_distance = M.nid * log_r(u32_to_unit(rng_bits(rng, c)));
-  if (hit_distance > distance_inside) return false;
-  t_out = t1 + hit_distance / r_length;
-  return true;
 }
 // The random unit normal of a medium hit (same sub-stream, draws 1..).
 DEV f3 medium_normal(const Rng& rng, uint32_t midx, uint32_t depth) {
