@@ -80,6 +80,10 @@ def parse_args():
     ap.add_argument("--camera-preset", default="default", choices=["default", "interior", "closeup"],
                     help="STRESS variants of the stand-ins, reported beside the headline, never instead of it: c3/c4 'interior' (under the gallery, "
                          "looking along the colonnade: every camera ray hits), c5 'closeup' (the statue fills the frame, glass in front of metal)")
+    ap.add_argument("--mesh-preset", default="regular", choices=["regular", "heterogeneous"],
+                    help="c3/c4: 'heterogeneous' = the same atrium with the triangle statistics of a hand-modelled asset (large wall triangles, "
+                         "long thin rails and rods, rotated drapes and arches, ornament clusters 1000x smaller): the STRESS mesh for the tree "
+                         "builder, reported beside the headline, never instead of it")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = the workload's total spp split by tiles over the ranks (default); weak = that spp per GPU")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel of the job (strong) / per GPU (weak); default: the workload's")
@@ -292,6 +296,8 @@ def pmc_passes(args, spp):
                 cmd += ["--hdri"]
             if args.camera_preset != "default":
                 cmd += ["--camera-preset", args.camera_preset]
+            if args.mesh_preset != "regular":
+                cmd += ["--mesh-preset", args.mesh_preset]
             if args.obj:
                 cmd += ["--obj", args.obj] + (["--camera", args.camera] if args.camera else []) + (["--light", args.light] if args.light else [])
             try:
@@ -325,6 +331,8 @@ def make_scene(args, spp_total):
     preset = args.camera_preset
     if preset != "default" and not ((wl in ("c3", "c4") and preset == "interior") or (wl == "c5" and preset == "closeup")) or (preset != "default" and args.obj):
         raise SystemExit(f"--camera-preset {preset} does not exist for workload {wl}")
+    if args.mesh_preset != "regular" and (wl not in ("c3", "c4") or args.obj):
+        raise SystemExit(f"--mesh-preset {args.mesh_preset} does not exist for workload {wl}")
     if args.obj:
         cam = light = None
         if args.camera:
@@ -338,8 +346,10 @@ def make_scene(args, spp_total):
     elif wl in ("c3", "c4"):
         name = (f"{wl.upper()} Sponza-class procedural atrium (stand-in: the real sponza.obj is not available offline; --obj takes one), "
                 f"{scenes.SPONZA_TRIANGLES} triangles, 24 Lambertian materials (8 image-textured), 1 quad light + sky" +
-                (" - STRESS camera 'interior' (under the gallery along the colonnade; not the headline view)" if preset == "interior" else ""))
-        make = lambda rc: scenes.sponza_like(rc, camera=preset)
+                (" - STRESS camera 'interior' (under the gallery along the colonnade; not the headline view)" if preset == "interior" else "") +
+                (" - STRESS mesh 'heterogeneous' (large wall triangles, long thin rails and rods, rotated drapes and arches, ornament clusters "
+                 "> 1000x smaller; not the headline mesh)" if args.mesh_preset == "heterogeneous" else ""))
+        make = lambda rc: scenes.sponza_like(rc, camera=preset, mesh=args.mesh_preset)
     elif wl == "c5":
         name = (f"C5 statue-class displaced mesh (stand-in), ~{scenes.STATUE_TRIANGLES} triangles, Metal(0.1) + Dielectric(1.5), 1 quad light" +
                 (" + procedural 2048x1024 HDR environment map (EXTENSION: not in the reference)" if args.hdri else "") +
@@ -480,6 +490,8 @@ def worker(args):
                                                            if world > 1 else "(single rank: un-permute only)")},
             "mrays_per_s": round(value * rays_per_sample, 2),
             "rays_per_sample": round(rays_per_sample, 4),
+            "node_visits_per_ray": round(st["node_visits"] / max(1, st["rays"]), 3),
+            "primitive_tests_per_ray": round((st["triangle_tests"] + st["quad_tests"] + st["sphere_tests"]) / max(1, st["rays"]), 3),
             "primary_hit_fraction": round(pst["primary_hit_fraction"], 4),
             "rays_per_path_histogram": {k: round(v, 4) for k, v in pst["rays_per_path_histogram"].items()},
             "rays_per_sample_note": "the open-roofed atrium ends most paths on the sky after ~3 rays; a closed interior costs several "

@@ -219,7 +219,13 @@ typedef struct SolCreateOptions {
   uint32_t size;            /* sizeof(SolCreateOptions): lets the struct grow                                         */
   int32_t world_tree;       /* SOL_TREE_*                                                                              */
   int32_t no_work_order_probe; /* 1: skip the 4-spp cost probe of the frame (heavy-first work order); for previews     */
-  int32_t reserved[5];
+  int32_t split_percent;    /* device build: triangle pre-splitting may add this many references, in percent of the primitive
+                               count (a split triangle gets one record per part of it). 0: the default - a budget of 30, used
+                               only when it shrinks the summed box area of the primitives below 85 % (meshes of uniform small
+                               triangles stay unsplit); > 0: that budget, always used; < 0: no pre-splitting                   */
+  int32_t reinsertion_rounds; /* device build: rounds of parallel reinsertion after the clustering (every node looks for the place
+                               where its sub-tree adds the least surface area; results do not change). 0: the default, < 0: none  */
+  int32_t reserved[3];
 } SolCreateOptions;
 int sol_scene_create_ex(const SolSceneDesc* desc, int device, const SolCreateOptions* options, SolScene** out);
 /* Seconds sol_scene_create spent in: [0] host tree candidates, [1] uploads, [2] device tree build, [3] probe renders. */
@@ -234,6 +240,12 @@ typedef struct SolSceneInfo {
   uint32_t tree_fallback;   /* 1: SOL_TREE_AUTO's device build failed and the host candidates were used (tree_note)    */
   char tree_name[32];       /* "device", "ref", "sah8", "sah16", "sah64"                                               */
   char tree_note[192];
+  uint32_t split_references; /* device build: references that triangle pre-splitting added (0: none, or not kept)            */
+  uint32_t split_triangles;  /* triangles with more than one reference                                                    */
+  float split_area_ratio;    /* summed box area of the primitives' references after / before pre-splitting (the splits are kept
+                                by default when this is below 0.85)                                                         */
+  uint32_t reinsertion_moves; /* device build: sub-trees the reinsertion rounds moved                                       */
+  float reinsertion_area_ratio; /* summed surface area of the binary tree's inner nodes after / before those rounds          */
 } SolSceneInfo;
 int sol_scene_info(const SolScene* scene, SolSceneInfo* out);
 
@@ -374,6 +386,10 @@ typedef struct SolTreeCheck {
   uint32_t leaf_mismatches;  /* primitive references missing from / surplus in the tree                           */
   uint32_t bad_empty_slots;  /* empty slots that are not (NONE reference, inverted box)                           */
   double inner_area, leaf_area; /* summed box areas of inner / primitive children (the surface-area cost estimate)  */
+  uint32_t n_extra_references; /* device build: references that pre-splitting added (a split triangle has several)     */
+  uint32_t n_split_triangles;  /* triangles with more than one reference                                              */
+  uint32_t split_uncovered;    /* sample points of split triangles that no reference box of their triangle holds (must be 0) */
+  uint32_t reserved;
 } SolTreeCheck;
 int sol_world_tree_check(const SolSceneDesc* desc, int use_sah, SolTreeCheck* out);
 

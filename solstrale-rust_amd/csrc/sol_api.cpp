@@ -45,6 +45,11 @@ SolDevOverrides sol_dev_overrides() {
   if (const char* bl = std::getenv("SOL_SAH_LIST"))  // experiment: other candidate sets, e.g. SOL_SAH_LIST=4,12,32
     for (const char* p = bl; *p;) { o.sah_bins.push_back(std::max(2, std::min(64, std::atoi(p)))); while (*p && *p != ',') ++p; if (*p) ++p; }
   o.ploc_radius = std::max(0, num("SOL_PLOC_R", 0));
+  o.split_percent = num("SOL_SPLIT", -1);
+  o.split_slack = num("SOL_SPLIT_SLACK", -1);
+  o.split_keep = num("SOL_SPLIT_KEEP", -1);
+  o.reinsert_rounds = num("SOL_REINSERT", -1);
+  o.reinsert_stride = std::max(0, num("SOL_REINSERT_STRIDE", 0));
   o.order_mode = num("SOL_ORDER", 2);
   o.switch_below = std::min(64, num("SOL_SWITCH", -1));
   o.max_bpc = num("SOL_MAX_BPC", -1);
@@ -52,6 +57,7 @@ SolDevOverrides sol_dev_overrides() {
   o.pool_slots = std::max(0, num("SOL_POOL_SLOTS", 0));
   o.wf_slots = std::max(0, num("SOL_WF_SLOTS", 0));
   o.wf_min_items = num("SOL_WF_MIN_ITEMS", -1);
+  if (const char* v = std::getenv("SOL_RCCL_LIB")) o.rccl_lib = v;
   o.verbose = std::getenv("SOL_VERBOSE") != nullptr;
   return o;
 }
@@ -204,6 +210,11 @@ int sol_scene_info(const SolScene* s, SolSceneInfo* out) {
   r.tree_fallback = s->tree_note.empty() ? 0u : 1u;
   std::snprintf(r.tree_name, sizeof r.tree_name, "%s", s->tree_name.c_str());
   std::snprintf(r.tree_note, sizeof r.tree_note, "%s", s->tree_note.c_str());
+  r.split_references = s->split_references;
+  r.split_triangles = s->split_triangles;
+  r.split_area_ratio = s->split_area_ratio;
+  r.reinsertion_moves = s->reinsertion_moves;
+  r.reinsertion_area_ratio = s->reinsertion_area_ratio;
   std::memcpy(out, &r, r.size);
   return SOL_OK;
 }

@@ -6,6 +6,15 @@
 // any order. Output: the device form of the 7-wide tree (DWide, sol_types.h) + the permutations of the primitive arrays, in
 // the same WideLayout record the host path produces, so everything downstream (upload, checks, kernels) is shared.
 //
+//   0. Triangle PRE-SPLITTING (after Karras & Aila 2013, "Fast parallel construction of high-quality bounding volume hierarchies",
+//      sec. 4.3): a triangle whose box straddles an important spatial-median plane of the scene - a plane of the Morton grid that
+//      separates groups of many primitives - is cut there, recursively, into several REFERENCES with tight boxes (the triangle
+//      clipped against the plane, Stich et al. 2009). Large wall triangles beside small ornament, long thin rails, diagonal rods:
+//      their one big, mostly empty box would otherwise overlap everything near it at every level of the tree. All references of
+//      a triangle name the same primitive (t, dfs): `better` keeps the closest hit whichever reference finds it, and a hit point lies
+//      inside the reference box of the part it belongs to, so results do not change (sol_trace.h). The priority rule
+//      (2^-level * (box area - ideal area))^(1/3) hands out a budget of extra references; parts stop splitting when no plane above
+//      the level of few-primitive cells crosses them.
 //   1. Morton codes of the box centres (63 bits) and a radix sort (rocPRIM).
 //   2. Binary tree by PLOC - parallel locally-ordered clustering (Meister & Bittner 2018): every cluster looks R neighbours
 //      to each side in the sorted order for the partner with the smallest joint surface, mutual choices merge; repeated until
@@ -21,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -75,6 +85,222 @@ __global__ void __launch_bounds__(BT) k_morton(const SolBuildPrim* __restrict__ 
                            zi = (unsigned long long)fminf(fmaxf(z, 0.f), 2097151.f);
   keys[i] = (spread21(xi) << 2) | (spread21(yi) << 1) | spread21(zi);
   vals[i] = i;
+}
+
+// ---- 0. pre-splitting --------------------------------------------------------------------------------------------------------
+constexpr int GRID_BITS = 21;              // the Morton grid of k_morton
+constexpr int GRID_CELLS = 1 << GRID_BITS;
+constexpr int SPLIT_CAP = 63;              // most splits of one triangle
+struct SplitGrid {
+  float lo[3], inv_cell[3], cell[3];
+  int level_max;   // a plane is worth a split when its level (0 = the scene's median plane on x, 1 = y, 2 = z, 3 = the quarter planes on x, ..) is below
+  float pad;
+};
+struct Piece {
+  float b[6];  // tight box of this part of the triangle
+  int q[6];    // grid cells it may still be cut in (narrowed at every split: a part never crosses the same plane twice)
+  int s;       // splits it may still spend
+};
+__device__ __forceinline__ void cell_range(const SplitGrid& G, const float* b, int* q) {
+  for (int a = 0; a < 3; ++a) {
+    int lo = (int)floorf((b[2 * a] - G.lo[a]) * G.inv_cell[a]), hi = (int)ceilf((b[2 * a + 1] - G.lo[a]) * G.inv_cell[a]) - 1;
+    lo = max(q[2 * a], min(GRID_CELLS - 1, max(0, lo)));
+    hi = min(q[2 * a + 1], min(GRID_CELLS - 1, max(0, hi)));
+    if (hi < lo) hi = lo;
+    q[2 * a] = lo; q[2 * a + 1] = hi;
+  }
+}
+// The most important plane crossing the cell range: its level, axis and position (first cell of the upper side); level 1 << 30: none.
+__device__ __forceinline__ int best_plane(const int* q, int& axis, int& pos) {
+  int best = 1 << 30;
+  for (int a = 0; a < 3; ++a) {
+    const int x = q[2 * a] ^ q[2 * a + 1];
+    if (!x) continue;
+    const int bit = 31 - __clz(x);
+    const int level = 3 * (GRID_BITS - 1 - bit) + a;
+    if (level < best) { best = level; axis = a; pos = (q[2 * a + 1] >> bit) << bit; }
+  }
+  return best;
+}
+__device__ __forceinline__ void tri_vertices(const DTri& T, float v[3][3]) {
+  v[0][0] = T.v0x; v[0][1] = T.v0y; v[0][2] = T.v0z;
+  v[1][0] = T.v0x + T.e1x; v[1][1] = T.v0y + T.e1y; v[1][2] = T.v0z + T.e1z;
+  v[2][0] = T.v0x + T.e2x; v[2][1] = T.v0y + T.e2y; v[2][2] = T.v0z + T.e2z;
+}
+__device__ __forceinline__ void grow_pt(float* b, const float* p) {
+  for (int a = 0; a < 3; ++a) { b[2 * a] = fminf(b[2 * a], p[a]); b[2 * a + 1] = fmaxf(b[2 * a + 1], p[a]); }
+}
+// Boxes of (triangle with x_axis <= s) and (triangle with x_axis >= s), each cut down to the parent part's box. False: a side is empty.
+__device__ bool clip_sides(const float v[3][3], const float* parent, int axis, float s, float* bl, float* br) {
+  const float inf = __builtin_huge_valf();
+  for (int a = 0; a < 3; ++a) { bl[2 * a] = br[2 * a] = inf; bl[2 * a + 1] = br[2 * a + 1] = -inf; }
+  for (int i = 0; i < 3; ++i) {
+    const float* vi = v[i];
+    const float* vj = v[(i + 1) % 3];
+    if (vi[axis] <= s) grow_pt(bl, vi);
+    if (vi[axis] >= s) grow_pt(br, vi);
+    if ((vi[axis] < s && vj[axis] > s) || (vi[axis] > s && vj[axis] < s)) {
+      const float t = (s - vi[axis]) / (vj[axis] - vi[axis]);
+      float p[3] = {vi[0] + (vj[0] - vi[0]) * t, vi[1] + (vj[1] - vi[1]) * t, vi[2] + (vj[2] - vi[2]) * t};
+      p[axis] = s;
+      grow_pt(bl, p);
+      grow_pt(br, p);
+    }
+  }
+  bool ok = true;
+  for (int a = 0; a < 3; ++a) {
+    bl[2 * a] = fmaxf(bl[2 * a], parent[2 * a]); bl[2 * a + 1] = fminf(bl[2 * a + 1], parent[2 * a + 1]);
+    br[2 * a] = fmaxf(br[2 * a], parent[2 * a]); br[2 * a + 1] = fminf(br[2 * a + 1], parent[2 * a + 1]);
+  }
+  bl[2 * axis + 1] = fminf(bl[2 * axis + 1], s);
+  br[2 * axis] = fmaxf(br[2 * axis], s);
+  for (int a = 0; a < 3; ++a) ok = ok && bl[2 * a] <= bl[2 * a + 1] && br[2 * a] <= br[2 * a + 1];
+  return ok;
+}
+__device__ __forceinline__ float longest(const float* b) { return fmaxf(b[1] - b[0], fmaxf(b[3] - b[2], b[5] - b[4])); }
+
+// Splits triangle `v` with a budget of `s` splits; calls emit(box) for every final part (tight box, unpadded). Explicit stack: the
+// side with MORE splits left is pushed, the other continued, so the stack never holds more than log2(s) + 1 parts.
+template <typename Emit>
+__device__ void split_triangle(const SplitGrid& G, const float v[3][3], int s, Emit emit) {
+  Piece stk[8];
+  int sp = 0;
+  Piece cur;
+  const float inf = __builtin_huge_valf();
+  for (int a = 0; a < 3; ++a) { cur.b[2 * a] = inf; cur.b[2 * a + 1] = -inf; cur.q[2 * a] = 0; cur.q[2 * a + 1] = GRID_CELLS - 1; }
+  for (int i = 0; i < 3; ++i) grow_pt(cur.b, v[i]);
+  cur.s = s;
+  cell_range(G, cur.b, cur.q);
+  for (;;) {
+    int axis = 0, pos = 0;
+    bool split = false;
+    Piece l, r;
+    if (cur.s > 0 && best_plane(cur.q, axis, pos) < G.level_max) {
+      const float sv = G.lo[axis] + (float)pos * G.cell[axis];
+      if (sv > cur.b[2 * axis] && sv < cur.b[2 * axis + 1] && clip_sides(v, cur.b, axis, sv, l.b, r.b)) {
+        for (int k = 0; k < 6; ++k) { l.q[k] = cur.q[k]; r.q[k] = cur.q[k]; }
+        l.q[2 * axis + 1] = pos - 1;
+        r.q[2 * axis] = pos;
+        cell_range(G, l.b, l.q);
+        cell_range(G, r.b, r.q);
+        const float wl = longest(l.b), wr = longest(r.b);
+        const int rest = cur.s - 1;
+        int sl = (wl + wr > 0.f) ? (int)floorf((float)rest * wl / (wl + wr) + 0.5f) : rest / 2;
+        sl = min(rest, max(0, sl));
+        l.s = sl;
+        r.s = rest - sl;
+        split = true;
+      } else {
+        // (the plane does not really cut this part - it lies on the part's face: the cell range was rounded outwards): take it out
+        // of the range and look again, without spending a split
+        if (sv <= cur.b[2 * axis]) cur.q[2 * axis] = max(cur.q[2 * axis], pos); else cur.q[2 * axis + 1] = min(cur.q[2 * axis + 1], pos - 1);
+        if (cur.q[2 * axis + 1] < cur.q[2 * axis]) cur.q[2 * axis + 1] = cur.q[2 * axis];
+        if (sv > cur.b[2 * axis] && sv < cur.b[2 * axis + 1]) cur.s = 0;  // (a clip that failed numerically: stop here)
+        continue;
+      }
+    }
+    if (split) {
+      const bool push_left = l.s > r.s;
+      if (sp < 8) { stk[sp++] = push_left ? l : r; cur = push_left ? r : l; continue; }
+      // (cannot happen for s <= SPLIT_CAP; be safe: stop splitting the larger side)
+      Piece big = push_left ? l : r;
+      emit(big.b);
+      cur = push_left ? r : l;
+      continue;
+    }
+    emit(cur.b);
+    if (sp == 0) break;
+    cur = stk[--sp];
+  }
+}
+
+// priority of a primitive for the split budget (0: not a triangle, or no plane worth a split crosses it)
+__global__ void __launch_bounds__(BT) k_split_priority(const SolBuildPrim* __restrict__ p, uint32_t n, const DTri* __restrict__ tris, uint32_t n_tris, SplitGrid G,
+                                                        float* __restrict__ prio) {
+  const uint32_t i = blockIdx.x * BT + threadIdx.x;
+  if (i >= n) return;
+  float pr = 0.f;
+  const uint32_t ref = p[i].ref;
+  if (SOL_REF_KIND(ref) == SOL_REF_TRIANGLE && SOL_REF_INDEX(ref) < n_tris) {
+    const DTri T = tris[SOL_REF_INDEX(ref)];
+    float v[3][3];
+    tri_vertices(T, v);
+    const float inf = __builtin_huge_valf();
+    float b[6] = {inf, -inf, inf, -inf, inf, -inf};
+    for (int k = 0; k < 3; ++k) grow_pt(b, v[k]);
+    int q[6] = {0, GRID_CELLS - 1, 0, GRID_CELLS - 1, 0, GRID_CELLS - 1};
+    cell_range(G, b, q);
+    int axis, pos;
+    const int level = best_plane(q, axis, pos);
+    if (level < G.level_max) {
+      const float dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+      const float a_box = 2.0f * (dx * dy + dy * dz + dz * dx);
+      const float nx = T.e1y * T.e2z - T.e1z * T.e2y, ny = T.e1z * T.e2x - T.e1x * T.e2z, nz = T.e1x * T.e2y - T.e1y * T.e2x;
+      const float a_ideal = fabsf(nx) + fabsf(ny) + fabsf(nz);
+      const float d = a_box - a_ideal;
+      if (d > 0.f && d < inf) pr = cbrtf(exp2f(-(float)level) * d);
+      if (!(pr > 0.f && pr < inf)) pr = 0.f;
+    }
+  }
+  prio[i] = pr;
+}
+__global__ void __launch_bounds__(BT) k_split_sum(const float* __restrict__ prio, uint32_t n, float D, unsigned long long* __restrict__ total) {
+  __shared__ unsigned int part[BT / 64];
+  const uint32_t i = blockIdx.x * BT + threadIdx.x;
+  unsigned int c = 0;
+  if (i < n) c = (unsigned int)fminf((float)SPLIT_CAP, floorf(D * prio[i]));
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int t = 0;
+    for (int k = 0; k < BT / 64; ++k) t += part[k];
+    if (t) atomicAdd(total, (unsigned long long)t);
+  }
+}
+// pass 1: how many parts each primitive becomes (1: not split); pass 2 (out != nullptr): the parts
+__global__ void __launch_bounds__(BT) k_split(const SolBuildPrim* __restrict__ p, uint32_t n, const DTri* __restrict__ tris, uint32_t n_tris, SplitGrid G,
+                                               const float* __restrict__ prio, float D, uint32_t* __restrict__ parts, const uint32_t* __restrict__ offset,
+                                               SolBuildPrim* __restrict__ out, uint32_t* __restrict__ extra_of, uint32_t* __restrict__ n_split, double* __restrict__ areas) {
+  const uint32_t i = blockIdx.x * BT + threadIdx.x;
+  if (i >= n) return;
+  const SolBuildPrim me = p[i];
+  const int s = (int)fminf((float)SPLIT_CAP, floorf(D * prio[i]));
+  const float a_me = box_area(me.box);
+  if (s <= 0) {
+    if (out) out[i] = me; else { parts[i] = 0u; if (a_me > 0.f && a_me < 1e30f) { atomicAdd(&areas[0], (double)a_me); atomicAdd(&areas[1], (double)a_me); } }
+    return;
+  }
+  const uint32_t tri = SOL_REF_INDEX(me.ref);
+  float v[3][3];
+  tri_vertices(tris[tri], v);
+  uint32_t k = 0;
+  float a_parts = 0.f;
+  const uint32_t base = out ? n + offset[i] : 0u;  // extra parts of primitive i: out[n + offset[i] ..], references n_tris + offset[i] ..
+  split_triangle(G, v, s, [&](const float* b) {
+    SolBuildPrim o;
+    for (int a = 0; a < 3; ++a) {  // padded like every primitive box, and never larger than the triangle's own padded box
+      o.box[2 * a] = fmaxf(b[2 * a] - G.pad, me.box[2 * a]);
+      o.box[2 * a + 1] = fminf(b[2 * a + 1] + G.pad, me.box[2 * a + 1]);
+    }
+    a_parts += box_area(o.box);
+    if (out) {
+      o.pad = 0;
+      if (k == 0) { o.ref = me.ref; out[i] = o; }
+      else {
+        const uint32_t e = offset[i] + (k - 1);
+        o.ref = SOL_MAKE_REF(SOL_REF_TRIANGLE, n_tris + e);
+        out[base + (k - 1)] = o;
+        extra_of[e] = tri;
+      }
+    }
+    ++k;
+  });
+  if (!out) {
+    parts[i] = k - 1u;
+    if (k > 1u) atomicAdd(n_split, 1u);
+    if (a_me > 0.f && a_me < 1e30f) { atomicAdd(&areas[0], (double)a_me); atomicAdd(&areas[1], (double)a_parts); }
+  }
 }
 
 // leaves = nodes 0 .. n-1 in sorted order
@@ -146,6 +372,203 @@ __global__ void __launch_bounds__(BT) k_compact(const uint32_t* __restrict__ out
                                                  uint32_t n, uint32_t* __restrict__ cluster_out) {
   const uint32_t i = blockIdx.x * BT + threadIdx.x;
   if (i < n && flag[i]) cluster_out[offset[i]] = out_node[i];
+}
+
+// ---- 2b. reinsertion ------------------------------------------------------------------------------------------------------------
+// Parallel reinsertion (after Meister & Bittner 2018, "Parallel reinsertion for bounding volume hierarchy optimization"): every
+// node x looks for the place in the tree where it - with its whole sub-tree - would sit at the smallest summed surface area, a
+// branch-and-bound walk that starts at its sibling and moves up pivot by pivot; the moves with a gain are then carried out, the
+// ones with the largest gain first where two of them touch the same nodes. Notation: p = parent(x), s = sibling(x); pivot P_k =
+// the k-th ancestor of p, O_k its child off x's path, R_k the box of P_k once x is gone. Putting x next to y (their new parent is
+// the node p, which leaves its old place to s) changes the summed area by
+//   A(x u y) - A(p)  -  sum_{j=1..k-1} (A(P_j) - A(R_j))  +  sum_{c on the way from O_k down to parent(y)} (A(c u x) - A(c))
+// for y below O_k (k = 0: below s); the pivot and everything above keep their boxes (same leaves below them).
+// A move rewrites the links of six nodes (x, p, s, parent(p), y, parent(y)): each is stamped with (gain, x) by a 64-bit atomic
+// maximum, and a move is carried out when all six stamps are its own and no node between y and the pivot is about to move with a
+// larger gain (k_reins_verify: what keeps simultaneous moves from tying the tree into a cycle). Moves that share only ancestors
+// commute; their gains were computed one at a time, so a round is greedy, not exact - the boxes are refitted after every round
+// and the summed area is watched. Every walk is bounded (a broken tree cannot hang a kernel) and k_validate checks the result.
+constexpr int REINS_MAX_UP = 96;       // pivots visited by one search
+constexpr int REINS_MAX_VISITS = 768;  // nodes looked at by one search
+constexpr int REINS_MAX_PATH = 256;    // nodes of one path
+__device__ __forceinline__ float area_of(const float* b) { return box_area(b); }
+__device__ __forceinline__ void load_box(const float* __restrict__ nbox, uint32_t i, float* b) {
+  for (int k = 0; k < 6; ++k) b[k] = nbox[(size_t)i * 6 + k];
+}
+__device__ __forceinline__ void unite(float* a, const float* b) {
+  for (int k = 0; k < 6; k += 2) { a[k] = fminf(a[k], b[k]); a[k + 1] = fmaxf(a[k + 1], b[k + 1]); }
+}
+__device__ __forceinline__ float union_area_n(const float* __restrict__ nbox, uint32_t i, const float* b) { return union_area(nbox + (size_t)i * 6, b); }
+
+__global__ void __launch_bounds__(BT) k_reins_find(uint32_t n_nodes, uint32_t n_leaves, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left,
+                                                    const uint32_t* __restrict__ right, const float* __restrict__ nbox, uint32_t phase, uint32_t stride,
+                                                    uint32_t* __restrict__ best_out, uint32_t* __restrict__ best_pivot, float* __restrict__ best_gain) {
+  const uint32_t x = blockIdx.x * BT + threadIdx.x;
+  if (x >= n_nodes) return;
+  best_out[x] = NONE;
+  best_gain[x] = 0.f;
+  if (stride > 1u && (x % stride) != phase) return;
+  const uint32_t p = parent[x];
+  if (p == NONE || parent[p] == NONE) return;  // (the root and its children stay: the root node keeps its index)
+  const uint32_t s = left[p] == x ? right[p] : left[p];
+  float bx[6];
+  load_box(nbox, x, bx);
+  const float a_x = area_of(bx), a_p = area_of(nbox + (size_t)p * 6);
+  if (!(a_x >= 0.f) || !(a_p < 1e30f)) return;
+  float R[6];
+  load_box(nbox, s, R);
+  float G = 0.f, d_best = 0.f;
+  uint32_t out = NONE, out_pivot = NONE;
+  uint32_t pivot = p, other = s;
+  int visits = 0;
+  for (int up = 0; up < REINS_MAX_UP; ++up) {
+    // ---- the sub-tree under `other`, depth first without a stack; I = growth of the nodes between `other` and cur's parent ----
+    uint32_t cur = other;
+    float I = 0.f;
+    for (;;) {
+      if (++visits > REINS_MAX_VISITS) break;
+      const float m = union_area_n(nbox, cur, bx);
+      if (cur != s) {  // (next to its own sibling is where x already is)
+        const float gain = a_p - m + G - I;
+        if (gain > d_best) { d_best = gain; out = cur; out_pivot = pivot; }
+      }
+      const float grow = m - area_of(nbox + (size_t)cur * 6);
+      if (cur >= n_leaves && a_p - a_x + G - I - grow > d_best) {  // something below cur may still be better
+        I += grow;
+        cur = left[cur];
+        continue;
+      }
+      // next node in depth-first order: up until a left child is found, then its right sibling
+      bool done = false;
+      for (;;) {
+        if (cur == other) { done = true; break; }
+        const uint32_t par = parent[cur];
+        if (cur == left[par]) { cur = right[par]; break; }
+        cur = par;
+        I -= union_area_n(nbox, cur, bx) - area_of(nbox + (size_t)cur * 6);
+      }
+      if (done) break;
+    }
+    if (visits > REINS_MAX_VISITS) break;
+    // ---- one pivot up ----
+    const uint32_t nxt = parent[pivot];
+    if (nxt == NONE) break;
+    if (pivot != p) G += area_of(nbox + (size_t)pivot * 6) - area_of(R);  // P_k (k >= 1) shrinks to R_k once the pivot moves above it
+    const uint32_t sib = left[nxt] == pivot ? right[nxt] : left[nxt];
+    float bs[6];
+    load_box(nbox, sib, bs);
+    unite(R, bs);
+    pivot = nxt;
+    other = sib;
+    // nothing at or above this pivot can gain more than A(p) - A(x) + G + what the pivots still to come may shrink by; the walk
+    // simply goes on to the root (bounded by REINS_MAX_UP), the searches below prune themselves
+  }
+  if (out != NONE && d_best > 1e-6f * a_p) {
+    best_out[x] = out;
+    best_pivot[x] = out_pivot;
+    best_gain[x] = d_best;
+  }
+}
+
+__device__ __forceinline__ unsigned long long reins_key(float gain, uint32_t x) { return ((unsigned long long)__float_as_uint(gain) << 32) | x; }  // (gain > 0: its bits order like the value)
+
+// The six nodes whose links a move rewrites: x, p = parent(x), s = sibling(x), g = parent(p), y and q = parent(y).
+template <typename F>
+__device__ bool reins_nodes(uint32_t x, uint32_t y, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, F f) {
+  const uint32_t p = parent[x];
+  if (p == NONE) return false;
+  const uint32_t g = parent[p], q = parent[y];
+  if (g == NONE || q == NONE) return false;
+  f(x); f(p); f(left[p] == x ? right[p] : left[p]); f(g); f(y); f(q);
+  return true;
+}
+__global__ void __launch_bounds__(BT) k_reins_lock(uint32_t n_nodes, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                    const uint32_t* __restrict__ best_out, const float* __restrict__ best_gain, unsigned long long* __restrict__ lock,
+                                                    unsigned long long* __restrict__ in_key) {
+  const uint32_t x = blockIdx.x * BT + threadIdx.x;
+  if (x >= n_nodes) return;
+  if (best_out[x] == NONE) { in_key[x] = 0ull; return; }
+  const unsigned long long key = reins_key(best_gain[x], x);
+  in_key[x] = key;
+  reins_nodes(x, best_out[x], parent, left, right, [&](uint32_t c) { atomicMax(&lock[c], key); });
+}
+// A move is carried out when (1) the six nodes it rewrites are stamped with its own key - two moves that touch a common node: the
+// larger gain wins - and (2) no node between y and the pivot is itself about to move with a larger gain: x landing inside a
+// sub-tree that lands inside x's own would tie the tree into a cycle, and of every such ring of moves the one in front of the
+// largest gain drops out here. (Moves that only share ancestors further up commute: each rewrites its own six nodes.)
+__global__ void __launch_bounds__(BT) k_reins_verify(uint32_t n_nodes, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                      uint32_t* __restrict__ best_out, const uint32_t* __restrict__ best_pivot, const float* __restrict__ best_gain,
+                                                      const unsigned long long* __restrict__ lock, const unsigned long long* __restrict__ in_key, uint8_t* __restrict__ ok) {
+  const uint32_t x = blockIdx.x * BT + threadIdx.x;
+  if (x >= n_nodes) return;
+  ok[x] = 0;
+  if (best_out[x] == NONE) return;
+  const unsigned long long key = reins_key(best_gain[x], x);
+  bool mine = true;
+  if (!reins_nodes(x, best_out[x], parent, left, right, [&](uint32_t c) { if (lock[c] != key) mine = false; })) mine = false;
+  const uint32_t pivot = best_pivot[x];
+  uint32_t c = best_out[x];
+  int steps = 0;
+  while (mine && c != pivot) {
+    if (in_key[c] > key) mine = false;
+    c = parent[c];
+    if (c == NONE || ++steps > REINS_MAX_PATH) mine = false;
+  }
+  ok[x] = mine ? 1 : 0;  // (read-only kernel as far as the tree goes: the moves are carried out by the next one)
+}
+__global__ void __launch_bounds__(BT) k_reins_apply(uint32_t n_nodes, uint32_t* __restrict__ parent, uint32_t* __restrict__ left, uint32_t* __restrict__ right,
+                                                     const uint32_t* __restrict__ best_out, const uint8_t* __restrict__ ok, uint32_t* __restrict__ n_moved) {
+  const uint32_t x = blockIdx.x * BT + threadIdx.x;
+  if (x >= n_nodes || !ok[x]) return;
+  const uint32_t y = best_out[x], p = parent[x], g = parent[p];
+  const uint32_t s = left[p] == x ? right[p] : left[p];
+  // s takes p's place under g
+  if (left[g] == p) left[g] = s; else right[g] = s;
+  parent[s] = g;
+  // p moves between y and y's parent (read after the step above: y's parent may be g)
+  const uint32_t q = parent[y];
+  if (left[q] == y) left[q] = p; else right[q] = p;
+  parent[p] = q;
+  left[p] = x;
+  right[p] = y;
+  parent[y] = p;
+  atomicAdd(n_moved, 1u);
+}
+// boxes of the inner nodes, bottom-up (the second child to arrive computes its parent)
+__global__ void __launch_bounds__(BT) k_refit(uint32_t n_leaves, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                               float* __restrict__ nbox, uint32_t* __restrict__ arrived, double* __restrict__ cost) {
+  const uint32_t i = blockIdx.x * BT + threadIdx.x;
+  if (i >= n_leaves) return;
+  uint32_t m = parent[i];
+  double sum = 0.;
+  int steps = 0;
+  while (m != NONE && ++steps < 4096) {
+    __threadfence();
+    if (atomicAdd(&arrived[m], 1u) == 0u) break;
+    __threadfence();
+    const float *ba = nbox + (size_t)left[m] * 6, *bb = nbox + (size_t)right[m] * 6;
+    float* bo = nbox + (size_t)m * 6;
+    for (int k = 0; k < 6; k += 2) { bo[k] = fminf(ba[k], bb[k]); bo[k + 1] = fmaxf(ba[k + 1], bb[k + 1]); }
+    sum += (double)box_area(bo);
+    m = parent[m];
+  }
+  if (sum > 0.) atomicAdd(cost, sum);
+}
+
+// After the reinsertion rounds: every inner node's children name it as their parent, are two different nodes, and its box is the
+// union of theirs; the root has no parent. [0] broken links, [1] wrong boxes.
+__global__ void __launch_bounds__(BT) k_validate(uint32_t n_nodes, uint32_t n_leaves, uint32_t root, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left,
+                                                  const uint32_t* __restrict__ right, const float* __restrict__ nbox, uint32_t* __restrict__ bad) {
+  const uint32_t m = blockIdx.x * BT + threadIdx.x;
+  if (m >= n_nodes) return;
+  if ((m == root) != (parent[m] == NONE)) atomicAdd(&bad[0], 1u);
+  if (m < n_leaves) return;
+  const uint32_t l = left[m], r = right[m];
+  if (l >= n_nodes || r >= n_nodes || l == r || parent[l] != m || parent[r] != m) { atomicAdd(&bad[0], 1u); return; }
+  for (int k = 0; k < 6; k += 2) {
+    const float lo = fminf(nbox[(size_t)l * 6 + k], nbox[(size_t)r * 6 + k]), hi = fmaxf(nbox[(size_t)l * 6 + k + 1], nbox[(size_t)r * 6 + k + 1]);
+    if (nbox[(size_t)m * 6 + k] != lo || nbox[(size_t)m * 6 + k + 1] != hi) { atomicAdd(&bad[1], 1u); break; }
+  }
 }
 
 // Collapse costs, bottom-up (sol_tree.h, WideBuilder::dp_compute): C(m, i) = cheapest representation of binary sub-tree m in at
@@ -427,33 +850,141 @@ struct Scratch {  // device allocations of one build, freed on every path
     if (e_ != hipSuccess) { err = std::string("launch of " #kernel ": ") + hipGetErrorString(e_); return false; } \
   } while (0)
 
-bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const float root_box[6], float pad, uint32_t emin, const uint32_t counts[3],
-                                 int ploc_radius, hipStream_t stream, SolDeviceTree& out, std::string& err) {
-  if (n == 0 || n > (SOL_WIDE_MAX_INDEX >> 1)) { err = "device tree build: primitive count out of range"; return false; }
+bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n_in, const float root_box[6], float pad, uint32_t emin, const uint32_t counts_in[3],
+                                 const DTri* tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, SolDeviceTree& out, std::string& err) {
+  if (n_in == 0 || n_in > (SOL_WIDE_MAX_INDEX >> 1)) { err = "device tree build: primitive count out of range"; return false; }
   Scratch S;
+  uint32_t n = n_in;
+  uint32_t counts[3] = {counts_in[0], counts_in[1], counts_in[2]};
+  SolBuildPrim* d_prims;
+  B_TRY(S.get(&d_prims, n_in));
+  B_TRY(hipMemcpyAsync(d_prims, prims, (size_t)n_in * sizeof(SolBuildPrim), hipMemcpyHostToDevice, stream));
+  float ext[3], inv[3];
+  for (int a = 0; a < 3; ++a) {
+    ext[a] = root_box[2 * a + 1] - root_box[2 * a];
+    inv[a] = (ext[a] > 0.f && ext[a] < 1e30f) ? 2097152.0f / ext[a] : 0.f;
+  }
+  // ---- 0. pre-splitting: d_prims (n_in) -> d_prims (n >= n_in), the extra references behind the originals ----
+  out.extra_of.clear();
+  out.split_triangles = 0;
+  out.split_area_ratio = 1.f;
+  const uint32_t budget = (tris && counts_in[0] && split.budget > 0.f) ? (uint32_t)std::min<double>((double)split.budget * n_in, (double)((SOL_WIDE_MAX_INDEX >> 1) - n_in)) : 0u;
+  if (budget > 0) {
+    SplitGrid G;
+    for (int a = 0; a < 3; ++a) { G.lo[a] = root_box[2 * a]; G.inv_cell[a] = inv[a]; G.cell[a] = ext[a] > 0.f && ext[a] < 1e30f ? ext[a] / 2097152.0f : 0.f; }
+    G.pad = pad;
+    int log2n = 0;
+    while ((2u << log2n) <= n_in) ++log2n;  // floor(log2 n)
+    G.level_max = std::max(0, std::min(3 * GRID_BITS, log2n - split.level_slack));
+    const uint32_t nb_in = (n_in + BT - 1) / BT;
+    DTri* d_tris;
+    float* prio;
+    uint32_t *parts, *poff, *n_split;
+    unsigned long long* total;
+    double* areas;
+    B_TRY(S.get(&d_tris, counts_in[0])); B_TRY(S.get(&prio, n_in)); B_TRY(S.get(&parts, n_in)); B_TRY(S.get(&poff, n_in)); B_TRY(S.get(&n_split, 1)); B_TRY(S.get(&total, 1));
+    B_TRY(S.get(&areas, 2));
+    B_TRY(hipMemcpyAsync(d_tris, tris, (size_t)counts_in[0] * sizeof(DTri), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_split_priority, dim3(nb_in), dim3(BT), 0, stream, d_prims, n_in, d_tris, counts_in[0], G, prio);
+    B_LAUNCHED(k_split_priority);
+    // the scale D of the priorities: the largest one whose split counts floor(D * p) stay within the budget (bisection; the
+    // sum is monotone in D). D_hi gives every triangle with a non-zero priority SPLIT_CAP splits.
+    float p_max = 0.f;
+    {
+      size_t red_bytes = 0;
+      float* d_max;
+      B_TRY(S.get(&d_max, 1));
+      B_TRY(rocprim::reduce(nullptr, red_bytes, prio, d_max, 0.f, (size_t)n_in, rocprim::maximum<float>(), stream));
+      char* red_tmp;
+      B_TRY(S.get(&red_tmp, red_bytes));
+      B_TRY(rocprim::reduce(red_tmp, red_bytes, prio, d_max, 0.f, (size_t)n_in, rocprim::maximum<float>(), stream));
+      B_TRY(hipMemcpyAsync(&p_max, d_max, 4, hipMemcpyDeviceToHost, stream));
+      B_TRY(hipStreamSynchronize(stream));
+    }
+    if (p_max > 0.f) {
+      auto total_at = [&](float D, unsigned long long& t) -> bool {
+        if (hipMemsetAsync(total, 0, 8, stream) != hipSuccess) return false;
+        hipLaunchKernelGGL(k_split_sum, dim3(nb_in), dim3(BT), 0, stream, prio, n_in, D, total);
+        if (hipGetLastError() != hipSuccess) return false;
+        if (hipMemcpyAsync(&t, total, 8, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+        return hipStreamSynchronize(stream) == hipSuccess;
+      };
+      // priorities span (p_max * 2^-21, p_max] in practice (cube roots); below D_lo nobody splits
+      double lo = 0.5 / p_max, hi = (double)(SPLIT_CAP + 1) / p_max * 4194304.0;
+      unsigned long long t = 0;
+      if (!total_at((float)hi, t)) { err = "device tree build: split budget search failed"; return false; }
+      float D = (float)hi;
+      if (t > budget) {
+        for (int it = 0; it < 48; ++it) {
+          const double mid = std::sqrt(lo * hi);
+          if (!total_at((float)mid, t)) { err = "device tree build: split budget search failed"; return false; }
+          if (t > budget) hi = mid; else lo = mid;
+          if (hi / lo < 1.0005) break;
+        }
+        D = (float)lo;
+      }
+      B_TRY(hipMemsetAsync(n_split, 0, 4, stream));
+      B_TRY(hipMemsetAsync(areas, 0, 16, stream));
+      hipLaunchKernelGGL(k_split, dim3(nb_in), dim3(BT), 0, stream, d_prims, n_in, d_tris, counts_in[0], G, prio, D, parts, (const uint32_t*)nullptr, (SolBuildPrim*)nullptr,
+                         (uint32_t*)nullptr, n_split, areas);
+      B_LAUNCHED(k_split);
+      size_t sb = 0;
+      B_TRY(rocprim::exclusive_scan(nullptr, sb, parts, poff, 0u, (size_t)n_in, rocprim::plus<uint32_t>(), stream));
+      char* stmp;
+      B_TRY(S.get(&stmp, sb));
+      B_TRY(rocprim::exclusive_scan(stmp, sb, parts, poff, 0u, (size_t)n_in, rocprim::plus<uint32_t>(), stream));
+      uint32_t last[2];
+      B_TRY(hipMemcpyAsync(&last[0], poff + (n_in - 1), 4, hipMemcpyDeviceToHost, stream));
+      B_TRY(hipMemcpyAsync(&last[1], parts + (n_in - 1), 4, hipMemcpyDeviceToHost, stream));
+      B_TRY(hipMemcpyAsync(&out.split_triangles, n_split, 4, hipMemcpyDeviceToHost, stream));
+      double h_areas[2] = {0., 0.};
+      B_TRY(hipMemcpyAsync(h_areas, areas, 16, hipMemcpyDeviceToHost, stream));
+      B_TRY(hipStreamSynchronize(stream));
+      const uint32_t extra = last[0] + last[1];
+      out.split_area_ratio = h_areas[0] > 0. ? (float)(h_areas[1] / h_areas[0]) : 1.f;
+      const bool keep = out.split_area_ratio <= split.max_area_ratio;
+      if (!keep) out.split_triangles = 0;
+      if (keep && extra > 0 && (uint64_t)n_in + extra <= (SOL_WIDE_MAX_INDEX >> 1)) {
+        SolBuildPrim* d_prims2;
+        uint32_t* d_extra_of;
+        B_TRY(S.get(&d_prims2, n_in + extra)); B_TRY(S.get(&d_extra_of, extra));
+        hipLaunchKernelGGL(k_split, dim3(nb_in), dim3(BT), 0, stream, d_prims, n_in, d_tris, counts_in[0], G, prio, D, parts, (const uint32_t*)poff, d_prims2, d_extra_of, n_split, areas);
+        B_LAUNCHED(k_split);
+        out.extra_of.resize(extra);
+        B_TRY(hipMemcpyAsync(out.extra_of.data(), d_extra_of, (size_t)extra * 4, hipMemcpyDeviceToHost, stream));
+        B_TRY(hipStreamSynchronize(stream));
+        d_prims = d_prims2;
+        n = n_in + extra;
+        counts[0] = counts_in[0] + extra;
+      }
+    }
+  }
   const uint32_t n_nodes = 2 * n - 1;
   const uint32_t nb = (n + BT - 1) / BT;
-  SolBuildPrim* d_prims;
   unsigned long long *keys, *keys2;
   uint32_t *vals, *order, *cl_a, *cl_b, *nn, *out_node, *flag, *offset, *left, *right, *parent, *arrived, *counters, *leaf_refs, *new_index[3];
   float* nbox;
   Dp* dp;
   DWide* wides;
   Frontier *fr_a, *fr_b;
-  B_TRY(S.get(&d_prims, n)); B_TRY(S.get(&keys, n)); B_TRY(S.get(&keys2, n)); B_TRY(S.get(&vals, n)); B_TRY(S.get(&order, n));
+  B_TRY(S.get(&keys, n)); B_TRY(S.get(&keys2, n)); B_TRY(S.get(&vals, n)); B_TRY(S.get(&order, n));
   B_TRY(S.get(&cl_a, n)); B_TRY(S.get(&cl_b, n)); B_TRY(S.get(&nn, n)); B_TRY(S.get(&out_node, n)); B_TRY(S.get(&flag, n)); B_TRY(S.get(&offset, n));
   B_TRY(S.get(&left, n_nodes)); B_TRY(S.get(&right, n_nodes)); B_TRY(S.get(&parent, n_nodes)); B_TRY(S.get(&arrived, n_nodes));
   B_TRY(S.get(&nbox, (size_t)n_nodes * 6)); B_TRY(S.get(&dp, n_nodes)); B_TRY(S.get(&counters, 8)); B_TRY(S.get(&leaf_refs, n));
   B_TRY(S.get(&wides, n)); B_TRY(S.get(&fr_a, n)); B_TRY(S.get(&fr_b, n));
   for (int a = 0; a < 3; ++a) { B_TRY(S.get(&new_index[a], counts[a])); B_TRY(hipMemsetAsync(new_index[a], 0xFF, (size_t)(counts[a] ? counts[a] : 1) * 4, stream)); }
-  B_TRY(hipMemcpyAsync(d_prims, prims, (size_t)n * sizeof(SolBuildPrim), hipMemcpyHostToDevice, stream));
   B_TRY(hipMemsetAsync(arrived, 0, (size_t)n_nodes * 4, stream));
-  // ---- 1. Morton order ----
-  float ext[3], inv[3];
-  for (int a = 0; a < 3; ++a) {
-    ext[a] = root_box[2 * a + 1] - root_box[2 * a];
-    inv[a] = (ext[a] > 0.f && ext[a] < 1e30f) ? 2097152.0f / ext[a] : 0.f;
+  if (split.want_boxes) {  // (sol_world_tree_check) every triangle reference's box, by expanded index
+    std::vector<SolBuildPrim> hp(n);
+    B_TRY(hipMemcpyAsync(hp.data(), d_prims, (size_t)n * sizeof(SolBuildPrim), hipMemcpyDeviceToHost, stream));
+    B_TRY(hipStreamSynchronize(stream));
+    const float inf = __builtin_huge_valf();
+    out.ref_box.assign((size_t)counts[0] * 6, 0.f);
+    for (uint32_t e = 0; e < counts[0]; ++e) { float* b = &out.ref_box[(size_t)e * 6]; b[0] = b[2] = b[4] = inf; b[1] = b[3] = b[5] = -inf; }
+    for (const SolBuildPrim& q : hp)
+      if (SOL_REF_KIND(q.ref) == SOL_REF_TRIANGLE && SOL_REF_INDEX(q.ref) < counts[0]) std::memcpy(&out.ref_box[(size_t)SOL_REF_INDEX(q.ref) * 6], q.box, 24);
   }
+  // ---- 1. Morton order ----
   hipLaunchKernelGGL(k_morton, dim3(nb), dim3(BT), 0, stream, d_prims, n, root_box[0], root_box[2], root_box[4], inv[0], inv[1], inv[2], keys, vals);
   B_LAUNCHED(k_morton);
   size_t tmp_bytes = 0, scan_bytes = 0;
@@ -494,6 +1025,60 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const fl
   }
   uint32_t root_node = 0;
   B_TRY(hipMemcpyAsync(&root_node, cin, 4, hipMemcpyDeviceToHost, stream));
+  // ---- 2b. reinsertion rounds ----
+  out.reinsertion_moves = 0;
+  out.area_before = out.area_after = 0.;
+  if (split.reinsertion_rounds > 0 && n >= 8) {
+    unsigned long long *lock, *in_key;
+    uint32_t *best_out, *best_pivot, *n_moved;
+    float* best_gain;
+    double* cost;
+    uint8_t* ok;
+    B_TRY(S.get(&in_key, n_nodes)); B_TRY(S.get(&ok, n_nodes));
+    B_TRY(S.get(&lock, n_nodes)); B_TRY(S.get(&best_out, n_nodes)); B_TRY(S.get(&best_pivot, n_nodes)); B_TRY(S.get(&best_gain, n_nodes)); B_TRY(S.get(&n_moved, 1)); B_TRY(S.get(&cost, 1));
+    const uint32_t gn = (n_nodes + BT - 1) / BT;
+    auto refit = [&](double& total) -> bool {
+      if (hipMemsetAsync(arrived, 0, (size_t)n_nodes * 4, stream) != hipSuccess || hipMemsetAsync(cost, 0, 8, stream) != hipSuccess) return false;
+      hipLaunchKernelGGL(k_refit, dim3(nb), dim3(BT), 0, stream, n, parent, left, right, nbox, arrived, cost);
+      if (hipGetLastError() != hipSuccess) return false;
+      if (hipMemcpyAsync(&total, cost, 8, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+      return hipStreamSynchronize(stream) == hipSuccess;
+    };
+    if (!refit(out.area_before)) { err = "device tree build: refit failed"; return false; }
+    out.area_after = out.area_before;
+    for (int round = 0; round < split.reinsertion_rounds; ++round) {
+      const uint32_t stride = (uint32_t)std::max(1, split.reinsertion_stride);
+      hipLaunchKernelGGL(k_reins_find, dim3(gn), dim3(BT), 0, stream, n_nodes, n, parent, left, right, nbox, (uint32_t)round % stride, stride, best_out, best_pivot, best_gain);
+      B_LAUNCHED(k_reins_find);
+      B_TRY(hipMemsetAsync(lock, 0, (size_t)n_nodes * 8, stream));
+      B_TRY(hipMemsetAsync(n_moved, 0, 4, stream));
+      hipLaunchKernelGGL(k_reins_lock, dim3(gn), dim3(BT), 0, stream, n_nodes, parent, left, right, best_out, best_gain, lock, in_key);
+      B_LAUNCHED(k_reins_lock);
+      hipLaunchKernelGGL(k_reins_verify, dim3(gn), dim3(BT), 0, stream, n_nodes, parent, left, right, best_out, best_pivot, best_gain, lock, in_key, ok);
+      B_LAUNCHED(k_reins_verify);
+      hipLaunchKernelGGL(k_reins_apply, dim3(gn), dim3(BT), 0, stream, n_nodes, parent, left, right, best_out, ok, n_moved);
+      B_LAUNCHED(k_reins_apply);
+      uint32_t moved = 0;
+      B_TRY(hipMemcpyAsync(&moved, n_moved, 4, hipMemcpyDeviceToHost, stream));
+      double total = 0.;
+      if (!refit(total)) { err = "device tree build: refit failed"; return false; }
+      out.reinsertion_moves += moved;
+      out.area_after = total;
+      if (split.verbose) std::fprintf(stderr, "[solstrale] reinsertion round %d: %u moves, summed inner area %.6g (start %.6g)\n", round, moved, total, out.area_before);
+      if (moved == 0 && stride == 1) break;
+    }
+    B_TRY(hipMemsetAsync(arrived, 0, (size_t)n_nodes * 4, stream));  // (k_collapse_cost counts arrivals again)
+    B_TRY(hipMemsetAsync(n_moved, 0, 4, stream));
+    uint32_t* bad;
+    B_TRY(S.get(&bad, 2));
+    B_TRY(hipMemsetAsync(bad, 0, 8, stream));
+    hipLaunchKernelGGL(k_validate, dim3(gn), dim3(BT), 0, stream, n_nodes, n, root_node, parent, left, right, nbox, bad);
+    B_LAUNCHED(k_validate);
+    uint32_t h_bad[2] = {0, 0};
+    B_TRY(hipMemcpyAsync(h_bad, bad, 8, hipMemcpyDeviceToHost, stream));
+    B_TRY(hipStreamSynchronize(stream));
+    if (h_bad[0] || h_bad[1]) { err = "device tree build: reinsertion left " + std::to_string(h_bad[0]) + " broken links and " + std::to_string(h_bad[1]) + " wrong boxes"; return false; }
+  }
   // ---- 3. collapse costs ----
   hipLaunchKernelGGL(k_collapse_cost, dim3(nb), dim3(BT), 0, stream, n, parent, left, right, nbox, arrived, dp);
   B_LAUNCHED(k_collapse_cost);

@@ -41,11 +41,18 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    const std::string forced = sol_dev_overrides().rccl_lib;  // SOL_RCCL_LIB: this library and no other (tests)
+    std::string why;
+    auto open = [&](const char* name) {
       r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.lib) break;
-    }
-    if (!r.lib) { r.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return; }
+      if (!r.lib) { const char* e = dlerror(); why = e ? e : "?"; }  // (dlerror() clears the message: read it once, right after the failure)
+      return r.lib != nullptr;
+    };
+    if (!forced.empty()) open(forced.c_str());
+    else
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+        if (open(name)) break;
+    if (!r.lib) { r.error = "cannot load librccl.so: " + why; return; }
     auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n; return p; };
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");

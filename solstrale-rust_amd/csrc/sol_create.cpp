@@ -20,9 +20,24 @@
 #include "sol_tree.h"
 
 // The world tree built on the GPU (sol_build.hip): primitives of the reference-shaped tree under `root_ref` (each once - a
-// shared sub-tree is the same geometry twice, one copy finds the same hits), clustered and collapsed on the current device.
+// shared sub-tree is the same geometry twice, one copy finds the same hits), pre-split, clustered and collapsed on the current device.
+// With pre-splitting a triangle may have SEVERAL references, each a record of its own in the permuted triangle array (implicit leaf
+// addresses want consecutive records): lay.old_of_new[0] then has more entries than the scene has triangles, several of them naming
+// the same triangle, and lay.new_of_old[0] names one of a triangle's records (any: they are copies). `split_info`: the build's
+// expanded references, for sol_world_tree_check.
+struct DeviceSplitInfo {
+  std::vector<uint32_t> tri_of_ref;  // expanded reference -> triangle
+  std::vector<uint32_t> ref_of_dev;  // device triangle index -> expanded reference
+  std::vector<float> ref_box;
+  uint32_t split_triangles = 0;
+  uint32_t extra_references = 0;
+  float area_ratio = 1.f;
+  uint32_t reinsertion_moves = 0;
+  double area_before = 0., area_after = 0.;
+};
 static int device_world_tree(const std::vector<DNode>& bin, uint32_t root_ref, const Box& root_box, float box_pad, const uint32_t counts[3],
-                             int ploc_radius, hipStream_t stream, WideLayout& lay, uint32_t& emin) {
+                             const std::vector<DTri>& tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, WideLayout& lay, uint32_t& emin,
+                             DeviceSplitInfo* split_info) {
   std::vector<SolBuildPrim> prims;
   if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) {
     SahBuilder col;
@@ -45,9 +60,61 @@ static int device_world_tree(const std::vector<DNode>& bin, uint32_t root_ref, c
   emin = WideBuilder::exponent_min(root_box, box_pad);
   SolDeviceTree dt;
   std::string err;
-  if (!sol_build_world_tree_device(prims.data(), (uint32_t)prims.size(), root_box.v, box_pad, emin, counts, ploc_radius, stream, dt, err)) return sol_fail(SOL_EDEVICE, "%s", err.c_str());
+  const bool have_tris = tris.size() == counts[0] && counts[0] > 0;
+  if (!sol_build_world_tree_device(prims.data(), (uint32_t)prims.size(), root_box.v, box_pad, emin, counts, have_tris ? tris.data() : nullptr, split, ploc_radius, stream, dt,
+                                   err))
+    return sol_fail(SOL_EDEVICE, "%s", err.c_str());
+  const std::vector<uint32_t> extra_of = std::move(dt.extra_of);
   if (!lay.adopt_device(std::move(dt.nodes), std::move(dt.leaf_refs), dt.new_of_old, dt.depth)) return sol_fail(SOL_EDEVICE, "%s", lay.error.c_str());
+  if (split_info) {
+    split_info->extra_references = (uint32_t)extra_of.size();
+    split_info->area_ratio = dt.split_area_ratio;
+    split_info->split_triangles = dt.split_triangles;
+    split_info->reinsertion_moves = dt.reinsertion_moves; split_info->area_before = dt.area_before; split_info->area_after = dt.area_after;
+  }
+  if (split_info && split.want_boxes) {
+    split_info->ref_of_dev = lay.old_of_new[0];
+    split_info->tri_of_ref.resize(counts[0] + extra_of.size());
+    for (uint32_t e = 0; e < split_info->tri_of_ref.size(); ++e) split_info->tri_of_ref[e] = e < counts[0] ? e : extra_of[e - counts[0]];
+    split_info->ref_box = std::move(dt.ref_box);
+  }
+  if (!extra_of.empty()) {  // expanded references -> triangles
+    if (lay.old_of_new[0].size() != (size_t)counts[0] + extra_of.size()) return sol_fail(SOL_EDEVICE, "device tree: split references lost");
+    for (uint32_t& o : lay.old_of_new[0])
+      if (o >= counts[0]) {
+        if (o - counts[0] >= extra_of.size() || extra_of[o - counts[0]] >= counts[0]) return sol_fail(SOL_EDEVICE, "device tree: bad split reference");
+        o = extra_of[o - counts[0]];
+      }
+    lay.new_of_old[0].resize(counts[0]);  // (a triangle's first reference keeps the triangle's own index)
+  }
   return SOL_OK;
+}
+
+// the triangles' vertices as the device will hold them (what pre-splitting clips)
+static std::vector<DTri> cast_triangles(const SolSceneDesc& d) {
+  std::vector<DTri> tris(d.n_triangles);
+  for (uint32_t i = 0; i < d.n_triangles; ++i) {
+    const SolTriangle& t = d.triangles[i];
+    DTri& o = tris[i];
+    o.v0x = (float)t.v0[0]; o.v0y = (float)t.v0[1]; o.v0z = (float)t.v0[2];
+    o.e1x = (float)t.v0v1[0]; o.e1y = (float)t.v0v1[1]; o.e1z = (float)t.v0v1[2];
+    o.e2x = (float)t.v0v2[0]; o.e2y = (float)t.v0v2[1]; o.e2z = (float)t.v0v2[2];
+    o.dfs = t.dfs_index; o.mat = t.material; o.area = (float)t.area;
+  }
+  return tris;
+}
+static SolSplitOptions split_options(const SolDevOverrides& ovr, const SolCreateOptions* opt) {
+  SolSplitOptions sp;  // (the default: a budget of 30 %, kept when the splits shrink the primitives' summed box area below 85 %)
+  if (opt && opt->split_percent < 0) sp.budget = 0.f;
+  else if (opt && opt->split_percent > 0) { sp.budget = (float)opt->split_percent / 100.0f; sp.max_area_ratio = 1.f; }  // an explicit budget is kept
+  if (ovr.split_percent >= 0) { sp.budget = (float)ovr.split_percent / 100.0f; sp.max_area_ratio = 1.f; }  // SOL_SPLIT (percent; 0 = off)
+  if (ovr.split_slack >= 0) sp.level_slack = ovr.split_slack;                                               // SOL_SPLIT_SLACK
+  if (ovr.split_keep >= 0) sp.max_area_ratio = (float)ovr.split_keep / 100.0f;                             // SOL_SPLIT_KEEP (percent)
+  if (opt && opt->reinsertion_rounds != 0) sp.reinsertion_rounds = std::max(0, opt->reinsertion_rounds);  // (0: the default, 8 rounds)
+  if (ovr.reinsert_rounds >= 0) sp.reinsertion_rounds = ovr.reinsert_rounds;                               // SOL_REINSERT (rounds; 0 = off)
+  if (ovr.reinsert_stride > 0) sp.reinsertion_stride = ovr.reinsert_stride;                                // SOL_REINSERT_STRIDE
+  sp.verbose = ovr.verbose;
+  return sp;
 }
 
 extern "C" {
@@ -74,13 +141,25 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
   WideLayout lay;
   uint32_t emin_used = 1;
   double inner_area = 0., leaf_area = 0.;
+  DeviceSplitInfo split;
+  std::vector<DTri> dev_tris;
   if (use_sah < 0) {  // the tree sol_build.hip builds on the GPU, checked like the host-built ones
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sol_fail(SOL_EDEVICE, "no HIP device available");
     HIP_TRY(hipSetDevice(0));
     const uint32_t counts[3] = {d->n_triangles, d->n_spheres, d->n_quads};
-    int rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, ovr.ploc_radius, nullptr, lay, emin_used);
+    dev_tris = cast_triangles(*d);
+    SolSplitOptions sp = split_options(ovr, nullptr);
+    sp.want_boxes = true;
+    int rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, dev_tris, sp, ovr.ploc_radius, nullptr, lay, emin_used, &split);
     if (rc) return rc;
+    // a split triangle has several references; each is expected once
+    for (uint32_t e = d->n_triangles; e < split.tri_of_ref.size(); ++e) {
+      auto it = expected.find(SOL_MAKE_REF(SOL_REF_TRIANGLE, split.tri_of_ref[e]));
+      if (it != expected.end()) it->second++; else out->leaf_mismatches++;
+    }
+    out->n_extra_references = (uint32_t)(split.tri_of_ref.size() - d->n_triangles);
+    out->n_split_triangles = split.split_triangles;
   } else {
     uint32_t bin_root = root_ref;
     if (use_sah) { Box b; sah.BINS = use_sah > 1 ? std::min((int)SahBuilder::MAX_BINS, use_sah) : 16; bin_root = sah.build(0, sah.prims.size(), 0, b); }
@@ -132,11 +211,17 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
         const uint32_t idx = WideLayout::base_prim(w) + (uint32_t)__builtin_popcount(lmask & below_mask);
         uint32_t ref = kind == SOL_LEAF_REFS ? (idx < lay.leaf_refs.size() ? lay.leaf_refs[idx] : 0u) : SOL_MAKE_REF(ref_kind_of[kind], idx);
         const int a = WideLayout::arr(SOL_REF_KIND(ref));
+        const uint32_t dev_idx = SOL_REF_INDEX(ref);  // (index into the permuted device array; for a listed reference too)
         if (a >= 0) ref = SOL_REF_INDEX(ref) < lay.old_of_new[a].size() ? SOL_MAKE_REF(SOL_REF_KIND(ref), lay.old_of_new[a][SOL_REF_INDEX(ref)]) : 0u;
         found[ref]++;
         out->n_leaf_refs++;
         auto it = prim_box.find(ref);
         below = it == prim_box.end() ? empty_box() : it->second;
+        if (a == 0 && !split.ref_box.empty() && dev_idx < split.ref_of_dev.size()) {
+          // (device build) the box of THIS reference of the triangle: the whole triangle's, or the part a pre-split gave it
+          const uint32_t e = split.ref_of_dev[dev_idx];
+          if ((size_t)e * 6 + 6 <= split.ref_box.size()) std::memcpy(below.v, &split.ref_box[(size_t)e * 6], 24);
+        }
       }
       bool ok = true;
       for (int a = 0; a < 3; ++a) {
@@ -150,11 +235,51 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
     return all;
   };
   walk(0, 0);
+  // Pre-split triangles: the boxes of a triangle's references must cover the triangle between them (a ray that hits the triangle
+  // at a point enters the reference box that holds the point). Checked on a fixed set of 67 points per split triangle: corners,
+  // edge mid-points, centroid and 60 low-discrepancy interior points.
+  if (split.tri_of_ref.size() > d->n_triangles) {
+    std::vector<std::vector<uint32_t>> refs_of(d->n_triangles);
+    for (uint32_t e = d->n_triangles; e < split.tri_of_ref.size(); ++e) {
+      const uint32_t t = split.tri_of_ref[e];
+      if (t >= d->n_triangles) { out->split_uncovered++; continue; }
+      if (refs_of[t].empty()) refs_of[t].push_back(t);
+      refs_of[t].push_back(e);
+    }
+    for (uint32_t t = 0; t < d->n_triangles; ++t) {
+      if (refs_of[t].empty()) continue;
+      const DTri& T = dev_tris[t];
+      const double v0[3] = {T.v0x, T.v0y, T.v0z}, e1[3] = {T.e1x, T.e1y, T.e1z}, e2[3] = {T.e2x, T.e2y, T.e2z};
+      for (int k = 0; k < 67; ++k) {
+        double u, v;
+        if (k < 7) { const double pts[7][2] = {{0, 0}, {1, 0}, {0, 1}, {.5, 0}, {0, .5}, {.5, .5}, {1. / 3, 1. / 3}}; u = pts[k][0]; v = pts[k][1]; }
+        else { u = std::fmod((k - 6) * 0.7548776662466927, 1.0); v = std::fmod((k - 6) * 0.5698402909980532, 1.0); if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; } }
+        const double p[3] = {v0[0] + u * e1[0] + v * e2[0], v0[1] + u * e1[1] + v * e2[1], v0[2] + u * e1[2] + v * e2[2]};
+        bool in_one = false;
+        for (uint32_t e : refs_of[t]) {
+          if ((size_t)e * 6 + 6 > split.ref_box.size()) continue;
+          const float* b = &split.ref_box[(size_t)e * 6];
+          if (p[0] >= b[0] && p[0] <= b[1] && p[1] >= b[2] && p[1] <= b[3] && p[2] >= b[4] && p[2] <= b[5]) { in_one = true; break; }
+        }
+        if (!in_one) out->split_uncovered++;
+      }
+    }
+  }
   // the permutations must be permutations
   for (int a = 0; a < 3; ++a) {
-    std::vector<uint8_t> seen(lay.old_of_new[a].size(), 0);
-    for (uint32_t o : lay.old_of_new[a]) { if (o >= seen.size() || seen[o]) out->leaf_mismatches++; else seen[o] = 1; }
-    if (lay.old_of_new[a].size() != lay.new_of_old[a].size()) out->leaf_mismatches++;
+    // (device build with pre-split triangles: the records are a permutation of the EXPANDED references, several of which are
+    // copies of one triangle; every triangle must find a copy of itself at new_of_old)
+    const bool expanded = a == 0 && split.ref_of_dev.size() > d->n_triangles;
+    const std::vector<uint32_t>& perm = expanded ? split.ref_of_dev : lay.old_of_new[a];
+    std::vector<uint8_t> seen(perm.size(), 0);
+    for (uint32_t o : perm) { if (o >= seen.size() || seen[o]) out->leaf_mismatches++; else seen[o] = 1; }
+    if (!expanded && lay.old_of_new[a].size() != lay.new_of_old[a].size()) out->leaf_mismatches++;
+    if (expanded) {
+      if (lay.new_of_old[0].size() != d->n_triangles || lay.old_of_new[0].size() != perm.size()) out->leaf_mismatches++;
+      else
+        for (uint32_t t = 0; t < d->n_triangles; ++t)
+          if (lay.new_of_old[0][t] >= lay.old_of_new[0].size() || lay.old_of_new[0][lay.new_of_old[0][t]] != t) out->leaf_mismatches++;
+    }
   }
   for (const auto& e : expected) {
     auto it = found.find(e.first);
@@ -456,7 +581,12 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     TreeCand c;
     c.name = "device";
     const uint32_t counts[3] = {d->n_triangles, d->n_spheres, d->n_quads};
-    rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, ovr.ploc_radius, s->stream, c.lay, c.emin);
+    DeviceSplitInfo si;
+    rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, tris, split_options(ovr, &opt), ovr.ploc_radius, s->stream, c.lay, c.emin, &si);
+    s->split_references = si.extra_references; s->split_triangles = si.split_triangles; s->split_area_ratio = si.area_ratio;
+    s->reinsertion_moves = si.reinsertion_moves; s->reinsertion_area_ratio = si.area_before > 0. ? (float)(si.area_after / si.area_before) : 1.f;
+    if (ovr.verbose) std::fprintf(stderr, "[solstrale] pre-splitting: %u triangles split into %u extra references, box area ratio %.3f%s\n", si.split_triangles, si.extra_references,
+                                  si.area_ratio, si.extra_references ? "" : " (not kept)");
     if (!rc) {
       c.depth = depth_of(c.lay);
       if (c.depth > stack_limit) rc = sol_fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", c.depth, stack_limit);
@@ -484,11 +614,11 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     if (c.emin + 31u + 24u > 254u) return sol_fail(SOL_EINVAL, "the scene is too large for the quantised world tree (extent beyond 2^100)");
     const WideLayout& L = c.lay;
     DevTree& t = c.dev;
-    std::vector<DTri> ptris(tris.size());
-    std::vector<DTriShade> pshade(tshade.size());
+    std::vector<DTri> ptris(L.old_of_new[0].size());  // (more records than triangles when the device build pre-split some: copies)
+    std::vector<DTriShade> pshade(L.old_of_new[0].size());
     std::vector<DQuad> pquads(quads.size());
     std::vector<DSphere> pspheres(spheres.size());
-    for (size_t i = 0; i < tris.size(); ++i) { ptris[i] = tris[L.old_of_new[0][i]]; pshade[i] = tshade[L.old_of_new[0][i]]; }
+    for (size_t i = 0; i < ptris.size(); ++i) { ptris[i] = tris[L.old_of_new[0][i]]; pshade[i] = tshade[L.old_of_new[0][i]]; }
     for (size_t i = 0; i < spheres.size(); ++i) pspheres[i] = spheres[L.old_of_new[1][i]];
     for (size_t i = 0; i < quads.size(); ++i) pquads[i] = quads[L.old_of_new[2][i]];
     std::vector<DNode> pnodes;

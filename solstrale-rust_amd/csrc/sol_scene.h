@@ -49,11 +49,17 @@ struct SolDevOverrides {
   double node_cost = 2.5;        // SOL_NODE_COST
   std::vector<int> sah_bins;     // SOL_SAH_LIST=4,12,.. (empty: 8, 16, 64)
   int ploc_radius = 0;           // SOL_PLOC_R (0: the builder's default)
+  int split_percent = -1;        // SOL_SPLIT: pre-split budget of the device build in percent of the primitive count (0 off; -1: not set)
+  int split_slack = -1;          // SOL_SPLIT_SLACK: levels below the one-primitive cells a plane must lie to be worth a split (-1: not set)
+  int split_keep = -1;           // SOL_SPLIT_KEEP: keep the splits when the summed box area falls below this percentage (-1: not set)
+  int reinsert_rounds = -1;      // SOL_REINSERT: reinsertion rounds of the device build (0 off; -1: not set)
+  int reinsert_stride = 0;       // SOL_REINSERT_STRIDE: every n-th node searches per round (0: not set)
   int order_mode = 2;            // SOL_ORDER: 0 no work-order probe, 1 heavy blocks first only, 2 + cost classes
   int switch_below = -1;         // SOL_SWITCH (-1: default)
   int max_bpc = -1;              // SOL_MAX_BPC
   int fine_tail = -2;            // SOL_FINE_TAIL (-2: not set)
   int pool_slots = 0, wf_slots = 0, wf_min_items = -1;  // SOL_POOL_SLOTS / SOL_WF_SLOTS / SOL_WF_MIN_ITEMS (v2 / v3)
+  std::string rccl_lib;          // SOL_RCCL_LIB: the communication library to dlopen instead of librccl.so.1 (tests)
   bool verbose = false;          // SOL_VERBOSE
 };
 SolDevOverrides sol_dev_overrides();
@@ -81,6 +87,9 @@ struct SolScene {
   std::vector<uint32_t> old_index[3];  // triangles / spheres / quads: device index -> index in the caller's SolSceneDesc arrays
   std::string tree_name;               // which world tree the handle walks ("ref", "sah8", .., "device")
   std::string tree_note;               // why it is not the one asked for (AUTO: the device build failed), else empty
+  uint32_t split_references = 0, split_triangles = 0;  // device build: what triangle pre-splitting added
+  float split_area_ratio = 1.f;
+  uint32_t reinsertion_moves = 0; float reinsertion_area_ratio = 1.f;  // device build: sub-trees moved; summed inner-node area after / before
   uint32_t* leaf_refs = nullptr;
   DNode* nodes = nullptr; DWide* wides = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
   DSphere* spheres = nullptr; DMedium* mediums = nullptr; DMat* mats = nullptr; DTex* texs = nullptr;

@@ -132,12 +132,15 @@ UNIQUE_ID_BYTES = 128
 
 
 class SolCreateOptions(C.Structure):
-    _fields_ = [("size", C.c_uint32), ("world_tree", C.c_int32), ("no_work_order_probe", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("size", C.c_uint32), ("world_tree", C.c_int32), ("no_work_order_probe", C.c_int32), ("split_percent", C.c_int32),
+                ("reinsertion_rounds", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class SolSceneInfo(C.Structure):
     _fields_ = [("size", C.c_uint32), ("stack_bound", C.c_uint32), ("lds_stack", C.c_uint32), ("spill_stack", C.c_uint32),
-                ("tree_fallback", C.c_uint32), ("tree_name", C.c_char * 32), ("tree_note", C.c_char * 192)]
+                ("tree_fallback", C.c_uint32), ("tree_name", C.c_char * 32), ("tree_note", C.c_char * 192),
+                ("split_references", C.c_uint32), ("split_triangles", C.c_uint32), ("split_area_ratio", C.c_float),
+                ("reinsertion_moves", C.c_uint32), ("reinsertion_area_ratio", C.c_float)]
 
 
 class SolPathStats(C.Structure):
@@ -147,7 +150,8 @@ class SolPathStats(C.Structure):
 class SolTreeCheck(C.Structure):
     _fields_ = [("n_wide", C.c_uint32), ("n_leaf_refs", C.c_uint32), ("n_primitives", C.c_uint32), ("depth", C.c_uint32),
                 ("max_children", C.c_uint32), ("box_violations", C.c_uint32), ("leaf_mismatches", C.c_uint32),
-                ("bad_empty_slots", C.c_uint32), ("inner_area", C.c_double), ("leaf_area", C.c_double)]
+                ("bad_empty_slots", C.c_uint32), ("inner_area", C.c_double), ("leaf_area", C.c_double),
+                ("n_extra_references", C.c_uint32), ("n_split_triangles", C.c_uint32), ("split_uncovered", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -58,15 +58,16 @@ def world_tree_check(scene, use_sah):
 class DeviceScene:
     """sol_scene_create .. sol_scene_destroy"""
 
-    def __init__(self, scene, device=0, world_tree=None, no_work_order_probe=False):
+    def __init__(self, scene, device=0, world_tree=None, no_work_order_probe=False, split_percent=0):
+        """split_percent: SolCreateOptions.split_percent (0: the default budget of the device build's triangle pre-splitting, < 0: none)."""
         self.lib = _abi.load_hip()
         self.scene = scene
         self.h = C.c_void_p()
-        if world_tree is None and not no_work_order_probe:
+        if world_tree is None and not no_work_order_probe and not split_percent:
             rc = self.lib.sol_scene_create(scene.desc_ptr, device, C.byref(self.h))
         else:
             opt = _abi.SolCreateOptions(size=C.sizeof(_abi.SolCreateOptions), world_tree=int(world_tree or 0),
-                                        no_work_order_probe=1 if no_work_order_probe else 0)
+                                        no_work_order_probe=1 if no_work_order_probe else 0, split_percent=int(split_percent))
             rc = self.lib.sol_scene_create_ex(scene.desc_ptr, device, C.byref(opt), C.byref(self.h))
         if rc != 0:
             self.h = None
@@ -112,7 +113,9 @@ class DeviceScene:
         r.size = C.sizeof(r)
         self._chk(self.lib.sol_scene_info(self.h, C.byref(r)))
         return {"stack_bound": int(r.stack_bound), "lds_stack": int(r.lds_stack), "spill_stack": int(r.spill_stack),
-                "tree_fallback": bool(r.tree_fallback), "tree_name": r.tree_name.decode(), "tree_note": r.tree_note.decode()}
+                "tree_fallback": bool(r.tree_fallback), "tree_name": r.tree_name.decode(), "tree_note": r.tree_note.decode(),
+                "split_references": int(r.split_references), "split_triangles": int(r.split_triangles), "split_area_ratio": float(r.split_area_ratio),
+                "reinsertion_moves": int(r.reinsertion_moves), "reinsertion_area_ratio": float(r.reinsertion_area_ratio)}
 
     def path_stats(self):
         """sol_path_stats of the last counted render: primary hit fraction and the path-length histogram (shares of the samples)."""

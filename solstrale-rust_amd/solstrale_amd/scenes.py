@@ -127,13 +127,161 @@ def _procedural_texture(kind, size, seed):
 SPONZA_TRIANGLES = 262267
 
 
-def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1024, n_materials=24, camera="default"):
+def _rot(axis, degrees):
+    """Rotation matrix about a coordinate axis (0 = x, 1 = y, 2 = z)."""
+    c, s_ = math.cos(math.radians(degrees)), math.sin(math.radians(degrees))
+    m = np.eye(3)
+    i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    m[i, i], m[i, j], m[j, i], m[j, j] = c, -s_, s_, c
+    return m
+
+
+def _placed(f, rot=None, origin=(0., 0., 0.), pivot=(0., 0., 0.)):
+    """f(u, v) -> (x, y, z) rotated by `rot` about `pivot`, then moved by `origin`."""
+    rot = np.eye(3) if rot is None else rot
+    pv, og = np.asarray(pivot, float), np.asarray(origin, float)
+
+    def g(u, v):
+        p = np.stack(f(u, v), axis=-1) - pv
+        q = p @ rot.T + pv + og
+        return q[..., 0], q[..., 1], q[..., 2]
+    return g
+
+
+def _strip(p0, p1, w):
+    """A flat strip from p0 to p1, `w` wide (vector): the long thin triangles of rails, cornices, rods."""
+    p0, p1, w = np.asarray(p0, float), np.asarray(p1, float), np.asarray(w, float)
+    return lambda u, v: tuple(p0[k] + (p1[k] - p0[k]) * u + w[k] * v for k in range(3))
+
+
+def _heterogeneous_atrium_parts(L, Wd, Hh):
+    """The atrium of `sponza_like` with the mesh statistics of a hand-modelled asset instead of uniform grids: a few
+    hundred LARGE triangles for floor, walls, galleries and roof; LONG THIN triangles (aspect 60:1 .. 300:1) for rails, balusters,
+    cornices and tie rods, the rods running diagonally through the hall; columns of moderate resolution under capitals made of
+    thousands of tiny leaves; arches, drapes and banners ROTATED off the coordinate axes; ornament clusters (lion heads, vases with
+    plants) whose triangles are > 1000 times smaller than the wall triangles. Returns [(surface f(u, v), nu, nv, material, uv tiling)]."""
+    parts = []
+
+    def plane(o, du, dv):
+        o, du, dv = np.array(o, float), np.array(du, float), np.array(dv, float)
+        return lambda u, v: tuple(o[k] + du[k] * u + dv[k] * v for k in range(3))
+
+    # ---- 1. large surfaces: 384 triangles of 3 x 3 units and the like ----
+    parts.append((plane((-L, 0, -Wd), (2 * L, 0, 0), (0, 0, 2 * Wd)), 10, 4, 0, (10, 4)))           # floor
+    parts.append((plane((-L, 0, -Wd), (2 * L, 0, 0), (0, Hh, 0)), 10, 4, 1, (10, 4)))                # wall z=-W
+    parts.append((plane((-L, 0, Wd), (2 * L, 0, 0), (0, Hh, 0)), 10, 4, 1, (10, 4)))                 # wall z=+W
+    parts.append((plane((-L, 0, -Wd), (0, 0, 2 * Wd), (0, Hh, 0)), 4, 4, 2, (4, 4)))                 # end wall x=-L
+    parts.append((plane((L, 0, -Wd), (0, 0, 2 * Wd), (0, Hh, 0)), 4, 4, 2, (4, 4)))                  # end wall x=+L
+    parts.append((plane((-L, 5.5, -Wd), (2 * L, 0, 0), (0, 0, 2.0)), 10, 1, 3, (10, 1)))             # gallery floor -z
+    parts.append((plane((-L, 5.5, Wd - 2.0), (2 * L, 0, 0), (0, 0, 2.0)), 10, 1, 3, (10, 1)))        # gallery floor +z
+    parts.append((plane((-L, Hh, -Wd), (2 * L, 0, 0), (0, 0, 2.5)), 10, 1, 4, (10, 1)))              # roof strip -z
+    parts.append((plane((-L, Hh, Wd - 2.5), (2 * L, 0, 0), (0, 0, 2.5)), 10, 1, 4, (10, 1)))         # roof strip +z
+    # ---- 2. long thin triangles ----
+    for side in (-1., 1.):
+        zr = side * (Wd - 2.0)
+        for y in (6.0, 6.2, 6.4, 6.6):                                                               # gallery rails: 7.5 x 0.05 (150:1)
+            parts.append((_strip((-L, y, zr), (L, y, zr), (0, 0.05, 0)), 4, 1, 16, (4, 1)))
+            parts.append((_strip((-L, y + 0.05, zr), (L, y + 0.05, zr), (0, 0, side * 0.05)), 4, 1, 16, (4, 1)))
+        for i in range(120):                                                                         # balusters: 1.1 x 0.018 (61:1)
+            x = -L + 0.125 + i * 0.25
+            parts.append((_strip((x, 5.5, zr), (x, 6.6, zr), (0.018, 0, 0)), 1, 1, 17, (1, 1)))
+        zw = side * (Wd - 0.02)
+        for y in (3.0, 5.3, 8.6, 11.6):                                                              # cornices on the long walls: three faces, 5 x 0.07 (71:1)
+            zf = zw - side * 0.05
+            parts.append((_strip((-L, y, zf), (L, y, zf), (0, 0.07, 0)), 6, 1, 18, (6, 1)))
+            parts.append((_strip((-L, y + 0.07, zf), (L, y + 0.07, zf), (0, 0, side * 0.05)), 6, 1, 18, (6, 1)))
+            parts.append((_strip((-L, y, zf), (L, y, zf), (0, 0, side * 0.05)), 6, 1, 18, (6, 1)))
+    for i in range(14):                                                                              # tie rods: diagonal through the hall, 12.5 x 0.04 (310:1)
+        x0 = -L + 1.0 + i * 2.0
+        a, bq = np.array((x0, 11.6, -Wd + 0.1)), np.array((x0 + 2.6, 10.4, Wd - 0.1))
+        for w in ((0, 0.04, 0), (0.04, 0, 0), (0.03, 0.03, 0)):
+            parts.append((_strip(a, bq, w), 1, 1, 19, (8, 1)))
+    for i in range(10):                                                                              # banner ropes from gallery to gallery, sagging
+        x0 = -L + 2.0 + i * 2.8
+
+        def rope(u, v, x0=x0, i=i):
+            return (x0 + 1.5 * u + 0.02 * v, 7.4 - 1.6 * np.sin(np.pi * u) + 0.0 * v, -(Wd - 2.0) + 2 * (Wd - 2.0) * u)
+        parts.append((rope, 12, 1, 19, (12, 1)))
+    # ---- 3. columns (moderate) with capitals made of tiny leaves ----
+    col_x = np.linspace(-L + 1.5, L - 1.5, 10)
+    for side in (-1., 1.):
+        for storey in range(2):
+            y0 = 0.0 if storey == 0 else 5.6
+            for i, cx in enumerate(col_x):
+                cz = side * (Wd - 2.0)
+
+                def column(u, v, cx=cx, cz=cz, y0=y0):
+                    r = 0.35 * (1.0 + 0.08 * np.sin(12 * np.pi * u)) * (1.0 - 0.1 * v)
+                    return cx + r * np.cos(2 * np.pi * u), y0 + 3.9 * v, cz + r * np.sin(2 * np.pi * u)
+                parts.append((column, 32, 16, 5 + (i % 3), (2, 3)))
+                for k in range(24):                                                                   # acanthus leaves: 6 x 6 cells of ~0.02
+                    ang = 2 * np.pi * k / 24
+
+                    def leaf(u, v, cx=cx, cz=cz, y0=y0, ang=ang, k=k):
+                        r = 0.33 + 0.16 * v + 0.05 * np.sin(np.pi * v) * (1 + 0.3 * np.sin(6 * np.pi * u))
+                        a2 = ang + (u - 0.5) * 0.24
+                        return cx + r * np.cos(a2), y0 + 3.9 + 0.3 * v - 0.05 * np.sin(np.pi * v) ** 2, cz + r * np.sin(a2)
+                    parts.append((leaf, 6, 6, 8 + (k % 3), (1, 1)))
+                if i + 1 < len(col_x):                                                                # arches, each yawed about its own vertical axis
+                    x1 = col_x[i + 1]
+
+                    def arch(u, v, x0=cx, x1=x1, cz=cz, y0=y0):
+                        ang = np.pi * u
+                        xm, rad = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
+                        return xm - rad * np.cos(ang), y0 + 4.2 + 0.9 * np.sin(ang), cz - 0.3 + 0.6 * v
+                    yaw = (7.0 if i % 2 == 0 else -9.0) * side
+                    parts.append((_placed(arch, _rot(1, yaw), pivot=(0.5 * (cx + x1), 0, cz)), 24, 4, 8 + (i % 4), (3, 1)))
+    # ---- 4. drapes: dense cloth, hung askew (yawed and tilted) ----
+    for i in range(6):
+        x0 = -L + 3.0 + i * 4.6
+        side = -1. if i % 2 == 0 else 1.
+
+        def drape(u, v, i=i):
+            return (2.2 * u, -3.0 * v + 0.1 * np.sin(6 * np.pi * u), 0.35 * np.sin(10 * np.pi * u + i) * (0.3 + v))
+        r = _rot(1, 18.0 + 7.0 * i) @ _rot(0, -8.0 + 3.0 * i)
+        parts.append((_placed(drape, r, origin=(x0, 5.4, side * (Wd - 2.6))), 96, 66, 12 + i, (2, 2)))
+    # ---- 5. ornament clusters: lion heads on the walls, vases with plants on the floor ----
+    for i in range(12):
+        side = -1. if i % 2 == 0 else 1.
+        cxh, cyh, czh = -L + 2.5 + (i // 2) * 5.0, 4.4 + 3.4 * ((i // 2) % 2), side * (Wd - 0.25)
+
+        def head(u, v, c=(cxh, cyh, czh), i=i):
+            th = np.pi * (0.02 + 0.96 * v)
+            r = 0.25 * (1.0 + 0.18 * np.sin(7 * 2 * np.pi * u + i) * np.sin(5 * th) + 0.08 * np.sin(23 * 2 * np.pi * u) * np.sin(17 * th))
+            return c[0] + r * np.sin(th) * np.cos(2 * np.pi * u), c[1] - r * np.cos(th), c[2] + r * np.sin(th) * np.sin(2 * np.pi * u)
+        parts.append((head, 64, 32, 20 + (i % 4), (1, 1)))
+    for i in range(8):
+        cxv, czv = -L + 3.7 + i * 3.3, (-1. if i % 2 else 1.) * 1.2
+
+        def vase(u, v, c=(cxv, czv)):
+            r = 0.12 + 0.22 * np.sin(np.pi * (0.15 + 0.8 * v)) ** 2
+            return c[0] + r * np.cos(2 * np.pi * u), 0.9 * v, c[1] + r * np.sin(2 * np.pi * u)
+        parts.append((vase, 32, 16, 22, (1, 1)))
+        for k in range(60):                                                                           # leaves: 0.9 x 0.03 strips in every direction
+            az, el = 360.0 * ((k * 0.618034) % 1.0), 25.0 + 50.0 * ((k * 0.754878) % 1.0)
+            d = _rot(1, az) @ _rot(2, el) @ np.array((1.0, 0.0, 0.0))
+
+            def leafstrip(u, v, c=(cxv, czv), d=d):
+                bend = -0.35 * u * u
+                w = np.cross(d, (0., 1., 0.))
+                w = w / (np.linalg.norm(w) + 1e-12) * 0.03
+                t = (1.0 - 0.8 * u) * (v - 0.5)
+                return (c[0] + 0.9 * d[0] * u + w[0] * t, 0.9 + 0.9 * d[1] * u + bend + w[1] * t, c[1] + 0.9 * d[2] * u + w[2] * t)
+            parts.append((leafstrip, 4, 1, 23, (1, 1)))
+    return parts
+
+
+def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1024, n_materials=24, camera="default", mesh="regular"):
     """C3 stand-in: an atrium (floor, two-storey walls, galleries, 2x10x2 columns with arches, hanging drapes, partial
     roof) tessellated to exactly `n_triangles` Lambertian triangles, `n_materials` materials of which 8 carry image
     textures, one Quad light above the roof opening and a constant sky background.
     camera: "default" looks across the atrium with the roof opening and the sky in view (paths end early: ~3 rays per sample);
     "interior" stands under the -z gallery and looks along the colonnade - floor, wall, gallery floor overhead and the columns fill
-    the frame, every camera ray hits, light arrives by bounces through the arches (the STRESS variant of the same geometry)."""
+    the frame, every camera ray hits, light arrives by bounces through the arches (the STRESS variant of the same geometry).
+    mesh: "regular" - every surface a uniform grid of near-equal small triangles (the headline workload since round 1; the
+    friendliest input a BVH builder can get); "heterogeneous" - the same hall with the triangle statistics of a hand-modelled asset
+    (_heterogeneous_atrium_parts: 2-triangle-per-3-metres walls beside leaves 20 000 times smaller, rails and rods of aspect 60:1 to
+    300:1, rotated drapes and arches): the STRESS mesh for the tree builder, reported beside the headline."""
     rc = render_config or RenderConfig(width=1920, height=1080, samples_per_pixel=512)
     b = SceneBuilder()
     mats = []
@@ -145,63 +293,71 @@ def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1
             mats.append(b.Lambertian(b.SolidColor(*c)))
     L, Wd, Hh = 15.0, 6.0, 12.0  # half length (x), half width (z), height (y)
     parts = []  # (weight, surface, material index, uv tiling)
-
-    def plane(o, du, dv):
-        o, du, dv = np.array(o, float), np.array(du, float), np.array(dv, float)
-        return lambda u, v: tuple(o[k] + du[k] * u + dv[k] * v for k in range(3))
-
-    parts.append((10., plane((-L, 0, -Wd), (2 * L, 0, 0), (0, 0, 2 * Wd)), 0, (10, 4)))          # floor
-    parts.append((8., plane((-L, 0, -Wd), (2 * L, 0, 0), (0, Hh, 0)), 1, (10, 4)))               # wall z=-W
-    parts.append((8., plane((-L, 0, Wd), (2 * L, 0, 0), (0, Hh, 0)), 1, (10, 4)))                # wall z=+W
-    parts.append((3., plane((-L, 0, -Wd), (0, 0, 2 * Wd), (0, Hh, 0)), 2, (4, 4)))               # end wall x=-L
-    parts.append((3., plane((L, 0, -Wd), (0, 0, 2 * Wd), (0, Hh, 0)), 2, (4, 4)))                # end wall x=+L
-    parts.append((4., plane((-L, 5.5, -Wd), (2 * L, 0, 0), (0, 0, 2.0)), 3, (10, 1)))            # gallery floor -z
-    parts.append((4., plane((-L, 5.5, Wd - 2.0), (2 * L, 0, 0), (0, 0, 2.0)), 3, (10, 1)))       # gallery floor +z
-    parts.append((3., plane((-L, Hh, -Wd), (2 * L, 0, 0), (0, 0, 2.5)), 4, (10, 1)))             # roof strip -z
-    parts.append((3., plane((-L, Hh, Wd - 2.5), (2 * L, 0, 0), (0, 0, 2.5)), 4, (10, 1)))        # roof strip +z
-    col_x = np.linspace(-L + 1.5, L - 1.5, 10)
-    for side in (-1., 1.):
-        for storey in range(2):
-            y0 = 0.0 if storey == 0 else 5.6
-            for i, cx in enumerate(col_x):
-                cz = side * (Wd - 2.0)
-
-                def column(u, v, cx=cx, cz=cz, y0=y0):
-                    r = 0.35 * (1.0 + 0.08 * np.sin(12 * np.pi * u)) * (1.0 - 0.1 * v)
-                    return cx + r * np.cos(2 * np.pi * u), y0 + 4.2 * v, cz + r * np.sin(2 * np.pi * u)
-
-                parts.append((2.2, column, 5 + (i % 3), (2, 3)))
-                if i + 1 < len(col_x):
-                    x1 = col_x[i + 1]
-
-                    def arch(u, v, x0=cx, x1=x1, cz=cz, y0=y0):
-                        ang = np.pi * u
-                        xm, rad = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
-                        return xm - rad * np.cos(ang), y0 + 4.2 + 0.9 * np.sin(ang), cz - 0.3 + 0.6 * v
-
-                    parts.append((1.2, arch, 8 + (i % 4), (3, 1)))
-    for i in range(6):  # drapes hanging from the galleries
-        x0 = -L + 3.0 + i * 4.6
-        side = -1. if i % 2 == 0 else 1.
-
-        def drape(u, v, x0=x0, side=side, i=i):
-            zc = side * (Wd - 2.3)
-            return (x0 + 2.2 * u, 5.4 - 3.0 * v + 0.1 * np.sin(6 * np.pi * u),
-                    zc + 0.35 * np.sin(10 * np.pi * u + i) * (0.3 + v))
-
-        parts.append((6., drape, 12 + i, (2, 2)))
-    total_w = sum(p[0] for p in parts)
     tris, uvs, mids = [], [], []
-    budget = n_triangles - 1  # one pennant triangle closes odd totals
     made = 0
-    for k, (w, f, m, tile) in enumerate(parts):
-        share = budget * w / total_w if k + 1 < len(parts) else budget - made
-        cells = max(1, int(share // 2))
-        nu = max(1, int(round(math.sqrt(cells * 2.0))))
-        nv = max(1, cells // nu)
-        t, uv = _grid(f, nu, nv, tile)
-        tris.append(t), uvs.append(uv), mids.append(np.full(len(t), mats[m % n_materials], dtype=np.int32))
-        made += len(t)
+    if mesh == "heterogeneous":
+        for f, nu, nv, m, tile in _heterogeneous_atrium_parts(L, Wd, Hh):
+            t, uv = _grid(f, nu, nv, tile)
+            tris.append(t), uvs.append(uv), mids.append(np.full(len(t), mats[m % n_materials], dtype=np.int32))
+            made += len(t)
+    elif mesh != "regular":
+        raise ValueError(f"unknown mesh preset {mesh!r}")
+    else:
+
+        def plane(o, du, dv):
+            o, du, dv = np.array(o, float), np.array(du, float), np.array(dv, float)
+            return lambda u, v: tuple(o[k] + du[k] * u + dv[k] * v for k in range(3))
+
+        parts.append((10., plane((-L, 0, -Wd), (2 * L, 0, 0), (0, 0, 2 * Wd)), 0, (10, 4)))          # floor
+        parts.append((8., plane((-L, 0, -Wd), (2 * L, 0, 0), (0, Hh, 0)), 1, (10, 4)))               # wall z=-W
+        parts.append((8., plane((-L, 0, Wd), (2 * L, 0, 0), (0, Hh, 0)), 1, (10, 4)))                # wall z=+W
+        parts.append((3., plane((-L, 0, -Wd), (0, 0, 2 * Wd), (0, Hh, 0)), 2, (4, 4)))               # end wall x=-L
+        parts.append((3., plane((L, 0, -Wd), (0, 0, 2 * Wd), (0, Hh, 0)), 2, (4, 4)))                # end wall x=+L
+        parts.append((4., plane((-L, 5.5, -Wd), (2 * L, 0, 0), (0, 0, 2.0)), 3, (10, 1)))            # gallery floor -z
+        parts.append((4., plane((-L, 5.5, Wd - 2.0), (2 * L, 0, 0), (0, 0, 2.0)), 3, (10, 1)))       # gallery floor +z
+        parts.append((3., plane((-L, Hh, -Wd), (2 * L, 0, 0), (0, 0, 2.5)), 4, (10, 1)))             # roof strip -z
+        parts.append((3., plane((-L, Hh, Wd - 2.5), (2 * L, 0, 0), (0, 0, 2.5)), 4, (10, 1)))        # roof strip +z
+        col_x = np.linspace(-L + 1.5, L - 1.5, 10)
+        for side in (-1., 1.):
+            for storey in range(2):
+                y0 = 0.0 if storey == 0 else 5.6
+                for i, cx in enumerate(col_x):
+                    cz = side * (Wd - 2.0)
+
+                    def column(u, v, cx=cx, cz=cz, y0=y0):
+                        r = 0.35 * (1.0 + 0.08 * np.sin(12 * np.pi * u)) * (1.0 - 0.1 * v)
+                        return cx + r * np.cos(2 * np.pi * u), y0 + 4.2 * v, cz + r * np.sin(2 * np.pi * u)
+
+                    parts.append((2.2, column, 5 + (i % 3), (2, 3)))
+                    if i + 1 < len(col_x):
+                        x1 = col_x[i + 1]
+
+                        def arch(u, v, x0=cx, x1=x1, cz=cz, y0=y0):
+                            ang = np.pi * u
+                            xm, rad = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
+                            return xm - rad * np.cos(ang), y0 + 4.2 + 0.9 * np.sin(ang), cz - 0.3 + 0.6 * v
+
+                        parts.append((1.2, arch, 8 + (i % 4), (3, 1)))
+        for i in range(6):  # drapes hanging from the galleries
+            x0 = -L + 3.0 + i * 4.6
+            side = -1. if i % 2 == 0 else 1.
+
+            def drape(u, v, x0=x0, side=side, i=i):
+                zc = side * (Wd - 2.3)
+                return (x0 + 2.2 * u, 5.4 - 3.0 * v + 0.1 * np.sin(6 * np.pi * u),
+                        zc + 0.35 * np.sin(10 * np.pi * u + i) * (0.3 + v))
+
+            parts.append((6., drape, 12 + i, (2, 2)))
+        total_w = sum(p[0] for p in parts)
+        budget = n_triangles - 1  # one pennant triangle closes odd totals
+        for k, (w, f, m, tile) in enumerate(parts):
+            share = budget * w / total_w if k + 1 < len(parts) else budget - made
+            cells = max(1, int(share // 2))
+            nu = max(1, int(round(math.sqrt(cells * 2.0))))
+            nv = max(1, cells // nu)
+            t, uv = _grid(f, nu, nv, tile)
+            tris.append(t), uvs.append(uv), mids.append(np.full(len(t), mats[m % n_materials], dtype=np.int32))
+            made += len(t)
     # filler: a strip of small pennants along the -z gallery rail until the exact count is reached
     missing = n_triangles - made
     if missing < 0:

@@ -76,3 +76,17 @@ def test_scene_validation_happens_before_the_device():
     with pytest.raises(DeviceError) as e:
         DeviceScene(sc)
     assert e.value.code == _abi.SOL_EINVAL
+
+
+def test_missing_communication_library_is_an_error_code_not_a_crash():
+    """A box without librccl.so (a single-GPU host that calls sol_comm_unique_id or bench.py --gpus N): SOL_EDEVICE with the loader's
+    message, not a crash (round 3's loader read dlerror() twice: the second read is NULL). In its own process: the loader runs once."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from solstrale_amd import DeviceError, comm_unique_id, _abi\n"
+            "try:\n    comm_unique_id()\n    print('LOADED')\n"
+            "except DeviceError as e:\n    print('CODE', e.code, e.msg)\n") % os.path.join(ROOT, "solstrale-rust_amd")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SOL_RCCL_LIB="/nonexistent/librccl.so.1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-500:])
+    assert r.stdout.startswith(f"CODE {_abi.SOL_EDEVICE} cannot load librccl.so:") and "nonexistent" in r.stdout, r.stdout

@@ -86,15 +86,40 @@ def test_random_scenes_build_sound_trees(seed):
         assert r["n_leaf_refs"] == r["n_primitives"]
 
 
+_hetero_cache = {}
+
+
+def _hetero(camera):  # (4 s of numpy per build: shared by the parametrisations)
+    if camera not in _hetero_cache:
+        _hetero_cache[camera] = scenes.sponza_like(RC, mesh="heterogeneous", texture_size=16, camera=camera)
+    return _hetero_cache[camera]
+
+
+DEVICE_SCENES = dict(SCENES)
+DEVICE_SCENES["atrium_heterogeneous"] = lambda: _hetero("default")
+DEVICE_SCENES["atrium_heterogeneous_interior"] = lambda: _hetero("interior")
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", list(SCENES))
-def test_device_built_tree_is_sound(name):
-    """The tree sol_build.hip builds ON THE GPU (SolCreateOptions.world_tree = SOL_TREE_DEVICE: Morton sort, PLOC clustering,
-    surface-area collapse, per-level emission) under the same structural check: every primitive reference once, every decoded
-    child box containing the padded primitive boxes below it, valid permutations of the primitive arrays."""
-    sc = SCENES[name]()
+@pytest.mark.parametrize("split", [None, "0", "100"], ids=["default_split", "no_split", "split_100"])
+@pytest.mark.parametrize("name", list(DEVICE_SCENES))
+def test_device_built_tree_is_sound(name, split, monkeypatch):
+    """The tree sol_build.hip builds ON THE GPU (SolCreateOptions.world_tree = SOL_TREE_DEVICE: triangle pre-splitting, Morton sort,
+    PLOC clustering, surface-area collapse, per-level emission) under the same structural check: every primitive reference once -
+    a pre-split triangle once per part -, every decoded child box containing the padded box of every reference below it, the boxes
+    of a split triangle's references covering the triangle between them, valid permutations of the primitive arrays."""
+    if split is not None:
+        monkeypatch.setenv("SOL_SPLIT", split)
+        monkeypatch.setenv("SOL_SPLIT_SLACK", "0" if split == "100" else "3")
+    sc = DEVICE_SCENES[name]()
     r = world_tree_check(sc, -1)
-    assert r["box_violations"] == 0 and r["leaf_mismatches"] == 0 and r["bad_empty_slots"] == 0, r
-    assert r["n_leaf_refs"] == r["n_primitives"] >= 2
+    assert r["box_violations"] == 0 and r["leaf_mismatches"] == 0 and r["bad_empty_slots"] == 0 and r["split_uncovered"] == 0, r
+    assert r["n_leaf_refs"] == r["n_primitives"] + r["n_extra_references"] and r["n_primitives"] >= 2
+    assert r["n_extra_references"] <= (r["n_primitives"] if split == "100" else 0.31 * r["n_primitives"])
+    assert (r["n_extra_references"] == 0) == (r["n_split_triangles"] == 0)
+    if split == "0":
+        assert r["n_extra_references"] == 0
+    if name.startswith("atrium_heterogeneous") and split != "0":
+        assert r["n_split_triangles"] > 500, r  # the walls, rails and rods are what pre-splitting is for
     assert 1 <= r["max_children"] <= 7 and r["depth"] >= 1
     assert r["n_wide"] <= max(1, (r["n_primitives"] + 1) // 2)

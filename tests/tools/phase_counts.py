@@ -8,7 +8,8 @@ import parity_util as pu
 from solstrale_amd import DeviceScene, RenderConfig, _abi, scenes
 
 if __name__ == "__main__":
-    make = {"c1": scenes.cornell_box, "c2": scenes.cornell_spheres, "c3": scenes.sponza_like, "c5": scenes.statue_like}
+    make = {"c1": scenes.cornell_box, "c2": scenes.cornell_spheres, "c3": scenes.sponza_like, "c5": scenes.statue_like,
+            "c3h": lambda rc: scenes.sponza_like(rc, mesh="heterogeneous"), "test": lambda rc: scenes.create_test_scene(RenderConfig(800, 400, 16))}
     for w in (sys.argv[1:] or ["c2", "c3", "c5"]):
         with DeviceScene(make[w](RenderConfig(1920, 1080, 16))) as ds:
             ds.render(0, 16, pu.SEED, counted=True)
