@@ -51,5 +51,9 @@ if __name__ == "__main__":
         run("spheres", scenes.cornell_spheres(RenderConfig(1920, 1080, spp, shader)), spp, phases=phases)
     if "c3" in which:
         run("sponza", scenes.sponza_like(RenderConfig(1920, 1080, spp, shader)), spp, phases=phases)
+    if "c3h" in which:
+        run("sponza_het", scenes.sponza_like(RenderConfig(1920, 1080, spp, shader), mesh="heterogeneous"), spp, phases=phases)
+    if "c5" in which:
+        run("statue", scenes.statue_like(RenderConfig(1920, 1080, spp, shader)), spp, phases=phases)
     if "test" in which:
         run("testscene", scenes.create_test_scene(RenderConfig(800, 400, spp, shader)), spp, phases=phases)

@@ -12,7 +12,8 @@ if __name__ == "__main__":
     ths = [int(a) for a in sys.argv[2:]] or [8, 12, 16, 20, 24, 28, 32, 40]
     for name, make in (("c1", scenes.cornell_box), ("c2", scenes.cornell_spheres), ("c3", scenes.sponza_like),
                        ("c3i", lambda rc: scenes.sponza_like(rc, camera="interior")), ("c5", scenes.statue_like),
-                       ("c5c", lambda rc: scenes.statue_like(rc, camera="closeup")), ("test", scenes.create_test_scene)):
+                       ("c5c", lambda rc: scenes.statue_like(rc, camera="closeup")), ("test", scenes.create_test_scene),
+                       ("c3h", lambda rc: scenes.sponza_like(rc, mesh="heterogeneous"))):
         with DeviceScene(make(RenderConfig(1920, 1080, spp))) as ds:
             row = []
             for th in ths:
