@@ -229,6 +229,14 @@ class Coord:
         self.store.set(f"{key}/{self.rank}", float(x))
         return max(self.store.get(f"{key}/{r}") for r in range(self.world))
 
+    def all(self, x):
+        """Every rank's value, by rank."""
+        if self.world == 1:
+            return [x]
+        key = self._next("all")
+        self.store.set(f"{key}/{self.rank}", x)
+        return [self.store.get(f"{key}/{r}") for r in range(self.world)]
+
 
 # ---- N > 1 without a launcher: this process becomes the parent of N rank processes ----------------------------------------
 def launch_ranks(args):
@@ -408,6 +416,7 @@ def worker(args):
     ds = DeviceScene(scene, local_rank)
     t_upload = time.time() - t0
     bt = ds.build_times()
+    tree_info = ds.info()
     rccl_ranks = None
     if world > 1:
         # the ONE communicator of the run lives behind the C ABI (sol_comm_init: ncclCommInitRank); the store only ships the id
@@ -417,6 +426,12 @@ def worker(args):
             ds.set_option(_abi.OPT_BALANCED_PARTITION, 1)
         ds.comm_init(rank, world, uid)
         rccl_ranks = world
+        # every rank derives the partition table from its own creation probe: they must agree, or blocks are rendered twice / not at
+        # all and the gather assembles a wrong frame without an error
+        part = ds.info()
+        parts = coord.all((part["partition_table"], part["partition_crc"]))
+        if len(set(parts)) != 1:
+            raise SystemExit(f"bench.py: the ranks disagree on the tile partition (table, checksum per rank: {parts})")
     acc = image = None
     image_ptr = 0  # (0: the scene's own image buffer)
     if torch is not None:
@@ -455,6 +470,16 @@ def worker(args):
     fence()
     dt = coord.max(time.perf_counter() - t0)
     k_ms, grid = ds.last_kernel_ms()  # duration of the last step's (last) render kernel (HIP events on its stream)
+    # what a scaling curve needs to explain itself: every rank's kernel time, and the gather timed on its own (one more, untimed,
+    # gather of the accumulators the last step left: host clock around sol_gather + synchronise, maximum over the ranks)
+    per_rank_kernel_ms = coord.all(round(k_ms, 3))
+    gather_ms = None
+    if world > 1:
+        fence()
+        tg = time.perf_counter()
+        ds.gather(image_ptr)
+        fence()
+        gather_ms = round(coord.max(time.perf_counter() - tg) * 1e3, 3)
     last_call_spp = spp - (spp - 1) // max_spp_call * max_spp_call
 
     # ---- counters: exact per-sample algorithmic bytes and rays from a counter-enabled run of the same kernels ----
@@ -498,17 +523,29 @@ def worker(args):
                                     "times more rays per sample - Mrays/s is the figure that transfers between scenes",
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "traffic_source": None,
+                         "binding": "valu_issue", "binding_achieved": None, "binding_peak": None, "binding_unit": None, "binding_frac": None,
+                         "binding_note": "what actually limits the kernel: vector-instruction issue x lane utilisation (roofline_valu, mirrored here when the "
+                                         "PMC passes ran); the hbm figures above are the contract's algorithmic-bytes bound, not the limit",
                          "frac_note": "ALGORITHMIC bytes (every node / primitive / texel record the search touches) per second; they are "
-                                      "served by L1/L2/Infinity Cache, so this is NOT HBM utilisation - see traffic_frac and roofline_valu",
+                                      "served by L1/L2/Infinity Cache, so this is NOT HBM utilisation (it exceeds what an HBM copy reaches, 6.3 TB/s, "
+                                      "and may pass 1.0) - see traffic_frac for what reaches the memory side and binding / roofline_valu for the limit",
                          "kernel": "sol_render_kernel", "kernel_ms": round(k_ms, 3), "grid_blocks": grid,
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
                          "samples_per_launch": int(launch_samples),
                          "counters_per_sample": {k: round(v / st["samples"], 4) for k, v in st.items() if k not in ("samples", "max_stack")}},
             "setup_s": {"scene_and_bvh_build_host": round(t_build, 2), "sol_scene_create": round(t_upload, 2),
                         **{"create_" + k: round(v, 3) for k, v in bt.items()}},
+            "world_tree": {"builder": tree_info["tree_name"], "presplit_extra_references": tree_info["split_references"],
+                           "presplit_triangles": tree_info["split_triangles"], "presplit_box_area_ratio": round(tree_info["split_area_ratio"], 4),
+                           "reinsertion_moves": tree_info["reinsertion_moves"], "reinsertion_area_ratio": round(tree_info["reinsertion_area_ratio"], 4),
+                           "note": "pre-splitting is kept only when it shrinks the summed box area of the primitives below 0.85 (regular meshes stay unsplit)"},
         }
         if world > 1:
             out["rccl_ranks"] = rccl_ranks
+            out["per_rank_kernel_ms"] = per_rank_kernel_ms
+            out["gather_ms"] = gather_ms
+            out["gather_note"] = "one extra sol_gather (grouped ncclSend / ncclRecv into rank 0 + un-permute) after the timed region, host clock incl. the barrier; the timed steps contain their own"
+            out["partition"] = {"table": bool(part["partition_table"]), "crc": part["partition_crc"], "agreed_by_all_ranks": True}
         if args.rehearse:
             out["rehearsal"] = "all ranks on cuda:0, sol_gather over the test-only transport stub (tests/stub_rccl): not a measurement"
     if args.rehearse and world > 1:
@@ -539,6 +576,10 @@ def worker(args):
             rf["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes of this run's workload at "
                                     f"{p_spp} spp, scaled per sample to this launch; L2<->fabric bytes, Infinity-Cache hits included")
             rf["traffic_frac"] = round(rf["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)
+            # the x2 is the guide's correction for wide coalesced reads; a divergent 16-byte gather is counted as it is (one 64-byte
+            # request per miss: profiles/r04_counter_questions.txt), and this kernel's reads are such gathers: the truth lies between
+            rf["traffic_uncorrected"] = int((g("FETCH_SIZE", 0.0) * 1024.0 + g("WRITE_SIZE", 0.0) * 1024.0) / p_samples * launch_samples)
+            rf["traffic_frac_range"] = [round(rf["traffic_uncorrected"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), rf["traffic_frac"]]
             clock = g("GRBM_GUI_ACTIVE", 0.0) / 8.0 / (info * 1e-9) if g("GRBM_GUI_ACTIVE") else 2.4e9
             k_cycles = info * 1e-9 * clock
             lane_util = g("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, g("SQ_ACTIVE_INST_VALU", 0.0) * 64.0)
@@ -547,6 +588,10 @@ def worker(args):
             busy4 = g("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (N_SIMD * k_cycles)
             inst_per_s = g("SQ_INSTS_VALU", 0.0) / (info * 1e-9)
             peak_inst = N_SIMD * clock / 2.0
+            rf["binding_achieved"] = round(inst_per_s * lane_util / 1e9, 2)
+            rf["binding_peak"] = round(peak_inst / 1e9, 2)
+            rf["binding_unit"] = "G wave64-instr/s x lane utilisation"
+            rf["binding_frac"] = round(inst_per_s * lane_util / peak_inst, 5)
             out["roofline_valu"] = {
                 "bound": "valu_issue", "achieved": round(inst_per_s * lane_util / 1e9, 2), "peak": round(peak_inst / 1e9, 2),
                 "unit": "G wave64-instr/s x lane utilisation", "frac": round(inst_per_s * lane_util / peak_inst, 5),
@@ -577,6 +622,9 @@ def worker(args):
 
 
 def main():
+    # RCCL / device-memory sharing between processes needs dmabuf IPC on this driver; the same setting for launcher-started ranks as
+    # for self-launched ones (it must be in the environment before the HIP runtime starts in this process)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))

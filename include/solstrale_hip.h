@@ -246,6 +246,10 @@ typedef struct SolSceneInfo {
                                 by default when this is below 0.85)                                                         */
   uint32_t reinsertion_moves; /* device build: sub-trees the reinsertion rounds moved                                       */
   float reinsertion_area_ratio; /* summed surface area of the binary tree's inner nodes after / before those rounds          */
+  uint32_t partition_table;  /* 1: the balanced partition table is in force (SOL_OPT_BALANCED_PARTITION was set AND the creation
+                                probe's block costs exist AND world > 1); 0: block b belongs to rank b % world                  */
+  uint32_t partition_crc;    /* checksum of the block -> (rank, local block) mapping in force: equal on every rank of a job, or the
+                                ranks render different partitions (each derives the table from its own probe)                     */
 } SolSceneInfo;
 int sol_scene_info(const SolScene* scene, SolSceneInfo* out);
 

@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB = os.path.join(HERE, "_build", "liboracle.so")
+LIB = os.environ.get("SOLSTRALE_ORACLE_LIB") or os.path.join(HERE, "_build", "liboracle.so")  # env: the sanitizer build (tests/tools/sanitize.sh)
 sys.path.insert(0, os.path.join(ROOT, "solstrale-rust_amd"))
 from solstrale_amd import _abi  # noqa: E402
 

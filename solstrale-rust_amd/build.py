@@ -94,7 +94,45 @@ def build_ab(force=False):
     return build(force=force, out_dir=BUILD_AB, ab_kernels=True)
 
 
+BUILD_SAN = os.path.join(HERE, "_build_san")
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+def build_sanitized():
+    """_build_san/: the three libraries with AddressSanitizer + UndefinedBehaviorSanitizer on their HOST code (CPU build only: device code
+    is not instrumented - no GPU sanitizer runs on this pool). One compiler (hipcc's clang) for all three so that one sanitizer
+    runtime serves the process; tests/tools/sanitize.sh runs the CPU suites under it with the runtime preloaded."""
+    os.makedirs(BUILD_SAN, exist_ok=True)
+    clang = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin", "clang++")
+    hip_lib = os.path.join(BUILD_SAN, "libsolstrale_hip.so")
+    flags = [f for f in HIP_FLAGS if f != "-O3"] + SAN_FLAGS + ["-fno-gpu-sanitize"]
+    jobs, objs = [], []
+    for src in HIP_SRC:
+        obj = os.path.join(BUILD_SAN, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if _stale(obj, [src] + HIP_HDR + ["build.py"]):
+            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or not os.path.exists(hip_lib):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-shared-libsan"] + SAN_FLAGS + ["-fno-gpu-sanitize"] + objs + ["-o", hip_lib, "-ldl"])
+    host_lib = os.path.join(BUILD_SAN, "libsolstrale_host.so")
+    if _stale(host_lib, HOST_DEPS + ["build.py"]) or os.path.getmtime(hip_lib) > os.path.getmtime(host_lib):
+        _run([clang, "-std=c++17", "-fPIC", "-shared", "-shared-libsan", "-Wall", "-Wextra", "-pthread"] + SAN_FLAGS + HOST_SRC +
+             ["-o", host_lib, "-L" + BUILD_SAN, "-lsolstrale_hip", "-Wl,-rpath,$ORIGIN"])
+    oracle_lib = os.path.join(BUILD_SAN, "liboracle.so")
+    odir = os.path.join(os.path.dirname(HERE), "oracle")
+    if not os.path.exists(oracle_lib) or any(os.path.getmtime(os.path.join(odir, f)) > os.path.getmtime(oracle_lib) for f in ("oracle.cpp", "oracle.h")):
+        _run([clang, "-std=c++17", "-fPIC", "-shared", "-shared-libsan", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra", "-pthread"] + SAN_FLAGS +
+             [os.path.join(odir, "oracle.cpp"), "-o", oracle_lib])
+    return BUILD_SAN
+
+
 if __name__ == "__main__":
+    if "--sanitize" in sys.argv:
+        print(build_sanitized())
+        sys.exit(0)
     build(force="--force" in sys.argv)
     if "--ab" in sys.argv:
         build_ab(force="--force" in sys.argv)

@@ -127,6 +127,12 @@ int sol_set_partition(SolScene* s, int rank, int world) {
   s->local_blocks.clear();
   s->S.block_of_local = nullptr;
   const bool table = s->balanced && world > 1 && s->block_work.size() == nb;
+  const uint32_t crc_before = s->partition_crc;
+  const bool had_sums = s->acc_own != nullptr && s->acc_floats > 0;
+  // Which block sits where: a checksum of the block -> (rank, local block) table that every rank must agree on (SolSceneInfo;
+  // bench.py compares it across the ranks before the timed region). Modulo partition: a function of (blocks, world) alone.
+  s->partition_table = table ? 1u : 0u;
+  s->partition_crc = 0x9E3779B9u * (uint32_t)world + nb;
   if (table) {
     std::vector<uint32_t> order(nb);
     for (uint32_t b = 0; b < nb; ++b) order[b] = b;
@@ -137,6 +143,7 @@ int sol_set_partition(SolScene* s, int rank, int world) {
       slot[order[j]] = r * max_blocks + g;
       if (r == (uint32_t)rank) s->local_blocks.push_back(order[j]);  // (local block g: the rounds come in order)
     }
+    for (uint32_t b = 0; b < nb; ++b) { s->partition_crc ^= slot[b] + 0x9E3779B9u + (s->partition_crc << 6) + (s->partition_crc >> 2); }
     // a rank without a block in the last, partial round has one local block less; local indices stay dense because every rank
     // takes part in every full round
     s->n_local_blocks = (uint32_t)s->local_blocks.size();
@@ -157,6 +164,13 @@ int sol_set_partition(SolScene* s, int rank, int world) {
     s->slot_of_block = nullptr;
   }
   size_t floats = (size_t)max_blocks * 64u * 3u;
+  // a different block -> slot mapping: sums already in the accumulators (and the auxiliary planes) lie in the old layout - cleared,
+  // so that a later sol_read cannot mix the two (the caller re-renders; a caller-bound accumulator was refused above)
+  if (had_sums && crc_before != s->partition_crc && floats == s->acc_floats && s->acc == s->acc_own) {
+    HIP_TRY(hipMemsetAsync(s->acc_own, 0, s->acc_floats * sizeof(float), s->stream));
+    for (int k = 0; k < 2; ++k)
+      if (s->aux[k] && s->aux_floats == s->acc_floats) HIP_TRY(hipMemsetAsync(s->aux[k], 0, s->aux_floats * sizeof(float), s->stream));
+  }
   if (floats != s->acc_floats || !s->acc_own) {
     if (s->acc_own) { hipFree(s->acc_own); s->acc_own = nullptr; }
     HIP_TRY(hipMalloc((void**)&s->acc_own, std::max<size_t>(floats * sizeof(float), 64)));
@@ -215,6 +229,8 @@ int sol_scene_info(const SolScene* s, SolSceneInfo* out) {
   r.split_area_ratio = s->split_area_ratio;
   r.reinsertion_moves = s->reinsertion_moves;
   r.reinsertion_area_ratio = s->reinsertion_area_ratio;
+  r.partition_table = s->partition_table;
+  r.partition_crc = s->partition_crc;
   std::memcpy(out, &r, r.size);
   return SOL_OK;
 }
@@ -252,10 +268,15 @@ int sol_scene_set_option(SolScene* s, int option, int64_t value) {
     case SOL_OPT_BALANCED_PARTITION:
       if (value != 0 && value != 1) return sol_fail(SOL_EINVAL, "SOL_OPT_BALANCED_PARTITION: 0 or 1");
       if (s->comm) return sol_fail(SOL_EINVAL, "SOL_OPT_BALANCED_PARTITION: set it before sol_comm_init (every rank the same)");
-      s->balanced = value != 0;
       HIP_TRY(hipSetDevice(s->device));
       if (s->acc != s->acc_own && s->world > 1) return sol_fail(SOL_EINVAL, "unbind the caller's accumulator before changing the partition");
-      return sol_set_partition(s, s->rank, s->world);
+      {  // (validated first; the flag changes only together with the tables that describe the partition)
+        const bool before = s->balanced;
+        s->balanced = value != 0;
+        const int rc = sol_set_partition(s, s->rank, s->world);
+        if (rc != SOL_OK) { s->balanced = before; return rc; }
+      }
+      return SOL_OK;
     case SOL_OPT_WORK_ORDER:
       s->order_enabled = value != 0;
       HIP_TRY(hipSetDevice(s->device));

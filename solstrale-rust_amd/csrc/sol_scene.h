@@ -99,6 +99,7 @@ struct SolScene {
   std::vector<uint32_t> block_cost;  // per 8x8 block (global index): rays of its longest item in the cost probe; empty: no ordering
   std::vector<uint32_t> block_work;  // per 8x8 block (global index): its rays in the cost probe (balanced partition)
   bool balanced = false;             // SOL_OPT_BALANCED_PARTITION
+  uint32_t partition_table = 0, partition_crc = 0;  // the partition in force: 1 = the balanced table (0: b % world), checksum of block -> slot
   std::vector<uint32_t> local_blocks;  // balanced partition: image block of every local block of this rank (empty: b = lb * world + rank)
   uint32_t* block_of_local_dev = nullptr; size_t block_of_local_cap = 0;
   uint32_t* slot_of_block = nullptr;   // balanced partition (device, all blocks): owner * blocks-per-buffer + local block; null: modulo

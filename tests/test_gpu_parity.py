@@ -606,6 +606,37 @@ def test_full_size_c3_properties():
     assert res["bad_pixels"] == 0 and res["max_rel"] <= pu.REL_TOL, res
 
 
+def test_full_size_c5_properties():
+    """configs[4] at its full size (statue stand-in, ~1.09 M triangles, Metal + Dielectric, 1920x1080 x 2048 spp = 128 chunks per
+    pixel, the heavy-first work order of the long glass items): additivity over 4 x 512 samples (sums, not means:
+    src/renderer/mod.rs:361-365), one rank's share of the 8-way job - rank 3 renders its tiles with all 2048 spp - against the whole
+    frame on the pixels it owns, and a 2048-spp oracle crop on the glass head. Mirrors test_full_size_c3_properties."""
+    sc = scenes.statue_like(RenderConfig(1920, 1080, 2048))
+    assert abs(sc.desc.n_triangles - scenes.STATUE_TRIANGLES) < 2000
+    with DeviceScene(sc) as ds:
+        ds.render(0, 2048, pu.SEED)
+        whole = ds.read()
+        ds.clear()
+        for f in range(0, 2048, 512):
+            ds.render(f, 512, pu.SEED)
+        parts = ds.read()
+        ds.clear()
+        ds.set_partition(3, 8)
+        ds.render(0, 2048, pu.SEED)
+        r3 = ds.read()
+    assert np.isfinite(whole).all() and (whole >= 0).all()
+    assert (whole == parts).all()
+    from solstrale_amd import tiles
+    owner, _ = tiles._slots(1920, 1080, 8)
+    owned = owner == 3
+    assert 0.12 < owned.mean() < 0.13 and (r3[owned] == whole[owned]).all() and not r3[~owned].any()
+    rect = (940, 120, 956, 136)  # 16 x 16 pixels of the glass head (x 830-1020, y 55-255): long refraction paths
+    ref, st = orc.render(sc, 0, 2048, pu.SEED, real=orc.ORC_F32, rect=rect)
+    assert st["rays"] > 2.5 * st["samples"]  # (glass: enter, leave, go on - the crop lies where the long items are; the frame's mean is 1.77)
+    res = pu.compare(whole, ref, 2048, rect=rect)
+    assert res["bad_pixels"] == 0 and res["max_rel"] <= pu.REL_TOL, res
+
+
 def test_c4_4k_crop_and_properties():
     """configs[3]: the Sponza-class scene at 3840x2160 x 1024 spp, tiles over 8 GPUs. On one GPU: two 128x128 oracle crops of the
     4K frame, additivity, and ONE RANK'S SHARE of the real job - rank 3 of 8 renders its tiles with all 1024 spp (64 chunks: the

@@ -4,7 +4,8 @@ Usage: python tests/tools/pmc_summary.py gpurun_out/<tag>_pmc <kernel-name-subst
 Counters are summed over every dispatch whose kernel name contains the substring (bench.py --steps 1 --warmup 0 launches
 the uncounted render kernel exactly once). Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM):
 FETCH_SIZE / WRITE_SIZE are KiB of L2<->fabric requests (Infinity-Cache hits included); on gfx950 FETCH_SIZE tallies a
-128-B request as 64 B, so reads are doubled for the "corrected" figure (an upper bound for narrow accesses)."""
+128-B request as 64 B, so reads are doubled for the "corrected" figure - an UPPER bound here: a divergent 16-byte gather is one
+64-byte request per miss and is counted as it is (profiles/r04_counter_questions.txt), so the truth lies between the two figures."""
 import csv
 import glob
 import json
@@ -61,7 +62,8 @@ def main():
         "l1_hit_rate (1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)": 1.0 - g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum"),
         "l2_hit_rate (TCC_HIT / (TCC_HIT + TCC_MISS))": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")),
         "ta_busy_frac (TA_BUSY_avr cycles / kernel cycles)": g("TA_BUSY_avr") / k_cycles,
-        "td_busy_frac (TD_TD_BUSY_sum / (256 CUs * kernel cycles))": g("TD_TD_BUSY_sum") / (256.0 * k_cycles),
+        # (TD_TD_BUSY is not reported: it reads 0.9 - 0.99 for ANY kernel with vector-memory requests in flight - a VALU-idle gather from
+        # HBM, from L2, a streaming read alike - profiles/r04_counter_questions.txt)
         "fabric_read_bytes_uncorrected (FETCH_SIZE KiB * 1024)": g("FETCH_SIZE") * 1024.0,
         "fabric_read_bytes_corrected_x2": g("FETCH_SIZE") * 2048.0,
         "fabric_write_bytes (WRITE_SIZE KiB * 1024)": g("WRITE_SIZE") * 1024.0,
