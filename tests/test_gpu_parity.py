@@ -631,7 +631,13 @@ def test_full_size_c5_properties():
     owned = owner == 3
     assert 0.12 < owned.mean() < 0.13 and (r3[owned] == whole[owned]).all() and not r3[~owned].any()
     rect = (940, 120, 956, 136)  # 16 x 16 pixels of the glass head (x 830-1020, y 55-255): long refraction paths
-    ref, st = orc.render(sc, 0, 2048, pu.SEED, real=orc.ORC_F32, rect=rect)
+    # (the oracle adds the samples of ONE call up in a float, one after the other; over 2048 of them that association alone drifts
+    # 1e-5 from the device's sums of 16-sample chunks - the same fp32 sample values either way - so it is asked for 8 x 256)
+    ref, rays, samples = None, 0, 0
+    for f in range(0, 2048, 256):
+        ref, st = orc.render(sc, f, 256, pu.SEED, real=orc.ORC_F32, rect=rect, out=ref)
+        rays, samples = rays + st["rays"], samples + st["samples"]
+    st = {"rays": rays, "samples": samples}
     assert st["rays"] > 2.5 * st["samples"]  # (glass: enter, leave, go on - the crop lies where the long items are; the frame's mean is 1.77)
     res = pu.compare(whole, ref, 2048, rect=rect)
     assert res["bad_pixels"] == 0 and res["max_rel"] <= pu.REL_TOL, res
