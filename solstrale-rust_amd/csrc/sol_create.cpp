@@ -413,6 +413,8 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
 
   // ---- tree ----
   const float box_pad = box_pad_for(*d);
+  // (the 7-wide node test's plane parameters must not overflow: sol_trace.h, wide_node_test; pad = largest |coordinate| * 2^-20)
+  if (!(box_pad * 1048576.0f <= 2.7487791e11f)) return sol_fail(SOL_EINVAL, "the scene's coordinates reach beyond 2^38 (%g): not supported by the fp32 search", (double)box_pad * 1048576.0);
   TreeBuilder tb(*d, box_pad);
   uint32_t root_ref;
   Box root_box;
@@ -576,24 +578,41 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   s->stream = s->own_stream;
   int rc;
+  std::vector<DeviceSplitInfo> dev_info;  // (per device candidate, in the order of `cands`)
   if (device_build) {
+    // The clustering radius of the device build decides little on average and a few per cent on any one scene, not monotonically (greedy
+    // clustering; MI355X, 1080p x 64 spp, ms with radius 8 / 16 / 32 / 64: C3 61.0 / 63.0 / 63.8 / 65.0, C2 37.1 / 35.7 / 34.7 / 37.3, C5
+    // 37.7 / 38.0 / 37.6 / 36.8, heterogeneous atrium 67.8 / 68.2 / 74.7 / 76.2 - profiles/r04_tree_ploc_radius.txt): SOL_TREE_AUTO builds
+    // the tree with radius 8, 16 and 32 and lets the counted probe choose, as the host path does among its candidates (the probe's
+    // cost - 2.5 per node visit, 1 per primitive test - ranks them as the render times do). An explicit SOL_TREE_DEVICE builds one
+    // tree (radius 16) for the shortest creation time; SOL_PLOC_R forces a radius.
     const auto t_dev0 = std::chrono::steady_clock::now();
-    TreeCand c;
-    c.name = "device";
+    std::vector<int> radii = {16};
+    if (ovr.ploc_radius > 0) radii = {ovr.ploc_radius};
+    else if (opt.world_tree == SOL_TREE_AUTO && ovr.bvh.empty()) radii = {16, 8, 32};
     const uint32_t counts[3] = {d->n_triangles, d->n_spheres, d->n_quads};
-    DeviceSplitInfo si;
-    rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, tris, split_options(ovr, &opt), ovr.ploc_radius, s->stream, c.lay, c.emin, &si);
-    s->split_references = si.extra_references; s->split_triangles = si.split_triangles; s->split_area_ratio = si.area_ratio;
-    s->reinsertion_moves = si.reinsertion_moves; s->reinsertion_area_ratio = si.area_before > 0. ? (float)(si.area_after / si.area_before) : 1.f;
-    if (ovr.verbose) std::fprintf(stderr, "[solstrale] pre-splitting: %u triangles split into %u extra references, box area ratio %.3f%s\n", si.split_triangles, si.extra_references,
-                                  si.area_ratio, si.extra_references ? "" : " (not kept)");
-    if (!rc) {
-      c.depth = depth_of(c.lay);
-      if (c.depth > stack_limit) rc = sol_fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", c.depth, stack_limit);
+    rc = SOL_OK;
+    for (int radius : radii) {
+      TreeCand c;
+      c.name = radii.size() > 1 ? "device" + std::to_string(radius) : "device";
+      DeviceSplitInfo si;
+      rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, tris, split_options(ovr, &opt), radius, s->stream, c.lay, c.emin, &si);
+      if (ovr.verbose) std::fprintf(stderr, "[solstrale] device tree (radius %d): pre-splitting %u triangles into %u extra references, box area ratio %.3f%s; %u reinsertion moves\n",
+                                    radius, si.split_triangles, si.extra_references, si.area_ratio, si.extra_references ? "" : " (not kept)", si.reinsertion_moves);
+      if (!rc) {
+        c.depth = depth_of(c.lay);
+        if (c.depth > stack_limit) rc = sol_fail(SOL_EDEPTH, "BVH depth %u exceeds the traversal stack (%d)", c.depth, stack_limit);
+      }
+      if (rc) {
+        if (!cands.empty()) { rc = SOL_OK; continue; }  // (a later candidate failed: the earlier ones stand)
+        break;
+      }
+      cands.push_back(std::move(c));
+      dev_info.push_back(si);
     }
     s->build_times[2] = seconds_since(t_dev0);
-    if (!rc) {
-      cands.push_back(std::move(c));
+    if (!cands.empty()) {
+      rc = SOL_OK;
     } else if (device_explicit) {
       return rc;
     } else {
@@ -605,7 +624,14 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
       s->build_times[0] += seconds_since(t_host0);
     }
   }
-  const bool calibrate = cands.size() > 1 && !device_build;
+  auto adopt_info = [&](size_t k) {  // what the chosen device candidate's build did
+    if (k >= dev_info.size()) return;
+    const DeviceSplitInfo& si = dev_info[k];
+    s->split_references = si.extra_references; s->split_triangles = si.split_triangles; s->split_area_ratio = si.area_ratio;
+    s->reinsertion_moves = si.reinsertion_moves; s->reinsertion_area_ratio = si.area_before > 0. ? (float)(si.area_after / si.area_before) : 1.f;
+  };
+  adopt_info(0);
+  const bool calibrate = cands.size() > 1;
   // everything that depends on the choice of the world tree: the tree itself, the permuted primitive arrays and every table of
   // references into them (DevTree); candidate 0 first, the others only if a probe has to decide
   const bool need_binary = d->n_mediums > 0;  // the 2-wide tree serves medium boundaries only
@@ -742,6 +768,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     if (hipStreamSynchronize(s->stream) != hipSuccess && !rc) rc = SOL_EDEVICE;
     swap_in(pick);
     s->tree_name = cands[pick].name;
+    adopt_info(pick);
     free_cands();
     if (rc) return rc;
     s->stats = SolStats{};

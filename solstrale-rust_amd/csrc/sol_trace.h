@@ -17,6 +17,7 @@
 // medium, whose interval includes negative t, walk the reference-shaped 2-wide tree (DNode).
 
 #define REF_DONE 0xFFFFFFFFu
+#define SOL_INV_CLAMP 1e18f  // |1 / direction| as the 7-wide node test sees it (wide_node_test: why 1e18)
 #define ALMOST_ZERO_F 1e-8f  // src/geo/vec3.rs:21
 #define RAY_MIN_F 0.001f     // RAY_INTERVAL.min (src/util/interval.rs:25-28)
 
@@ -266,9 +267,10 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
               __builtin_signbitf(t.inv.z), te))
       t.cur = REF_DONE;
   }
-  // A 7-wide search evaluates its slabs in t-space with the inverse direction clamped to +-1e30 (wide_node_test: an exactly zero
-  // direction component becomes the containment test it should be instead of NaN); clamped here, once per ray, not once per node
-  if (WIDE) t.inv = mk3(__builtin_amdgcn_fmed3f(t.inv.x, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(t.inv.y, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(t.inv.z, -1e30f, 1e30f));
+  // A 7-wide search evaluates its slabs in t-space with the inverse direction clamped to +-SOL_INV_CLAMP (wide_node_test: an exactly
+  // zero direction component becomes the containment test it should be instead of NaN); clamped here, once per ray, not once per node
+  if (WIDE) t.inv = mk3(__builtin_amdgcn_fmed3f(t.inv.x, -SOL_INV_CLAMP, SOL_INV_CLAMP), __builtin_amdgcn_fmed3f(t.inv.y, -SOL_INV_CLAMP, SOL_INV_CLAMP),
+                        __builtin_amdgcn_fmed3f(t.inv.z, -SOL_INV_CLAMP, SOL_INV_CLAMP));
 }
 
 // Decodes child `i` (compile-time) of a wide node and tests it; sets bit i of `hits` when the child must be visited.
@@ -283,8 +285,13 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
 // beyond the cull distance clamps to te' = tx' = 1, one wholly behind the origin to 0 = 0. (A box holding a primitive that a ray
 // really hits has te < tx by the builder's margin of three pads, 2.7 times the rounding error of this evaluation - sol_tree.h -, so
 // the strict comparison loses nothing; the scale is taken a millionth short of 1 / cull so that a tie at t = cull stays inside.)
-// NaN (an overflowing plane product) clamps to 0 under DX10_CLAMP: no constraint for a near plane; planes do not overflow for
-// |inv| <= 1e30 / t_min and node scales below 1e5.
+// NaN clamps to 0 under DX10_CLAMP: no constraint for a near plane. No plane parameter may OVERFLOW, or a box the ray is inside of
+// would read as culled (-inf + finite: far plane 0): with the inverse direction clamped to SOL_INV_CLAMP = 1e18 (trav_begin), the cull
+// scale at most 1 / RAY_MIN = 1e3 and the scene's coordinates below 2^38 (sol_scene_create refuses larger ones), the addend stays
+// below 2^39 * 1e21 = 5.5e32 and the slope - a node scale of at most 2^32 times the 2^24 of the subnormal halves - below 2^56 * 1e21 =
+// 7.2e37 < FLT_MAX. (Round 3 clamped to 1e30: an axis-parallel ray - direction component exactly 0 - lost real hits in
+// nodes further than ~3e5 from its origin, and whenever the node scale times the cull scale passed 3e8. A smaller clamp only makes
+// such a ray's test more conservative: the containment reading needs |plane - origin| * clamp * cull scale >= 1.)
 #define SOL_FMA_MIX_LO(d, h2, b, a) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0] clamp" : "=v"(d) : "v"(h2), "v"(b), "v"(a))
 #define SOL_FMA_MIX_HI(d, h2, b, a) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(d) : "v"(h2), "v"(b), "v"(a))
 #define SOL_FMA_MIX_x SOL_FMA_MIX_LO
@@ -316,11 +323,11 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
   const float scz = __uint_as_float((((meta >> 10) & 31u) + wide_emin) << 23);
   uint32_t miss = 0u;  // children are tested 6 .. 0, each shifting its bit in at the bottom: child i ends on bit i
   // An exactly zero direction component gives inv = inf, and A + q * B = -inf + inf = NaN for every plane: "no constraint",
-  // i.e. the ray would visit every node. Clamped to +-1e30 the axis becomes the containment test it should be (origin
+  // i.e. the ray would visit every node. Clamped to +-SOL_INV_CLAMP the axis becomes the containment test it should be (origin
   // inside the slab: planes at -+huge; outside: both planes at the same huge sign -> culled).
   // (units of the cull distance, a millionth short: see SOL_WIDE_CHILD; best t is a positive float or +inf, never NaN)
   const float rc = __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(t.h.t, RAY_MIN_F, 1e30f) * 1.000001f);
-  const float ivx = t.inv.x * rc, ivy = t.inv.y * rc, ivz = t.inv.z * rc;  // (t.inv: clamped to +-1e30 by trav_begin)
+  const float ivx = t.inv.x * rc, ivy = t.inv.y * rc, ivz = t.inv.z * rc;  // (t.inv: clamped to +-SOL_INV_CLAMP by trav_begin)
   const float ax = (h.x - t.o.x) * ivx, bx = scx * ivx;
   const float ay = (h.y - t.o.y) * ivy, by = scy * ivy;
   const float az = (h.z - t.o.z) * ivz, bz = scz * ivz;

@@ -90,3 +90,16 @@ def test_missing_communication_library_is_an_error_code_not_a_crash():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SOL_RCCL_LIB="/nonexistent/librccl.so.1"), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stderr[-500:])
     assert r.stdout.startswith(f"CODE {_abi.SOL_EDEVICE} cannot load librccl.so:") and "nonexistent" in r.stdout, r.stdout
+
+
+def test_scene_extent_is_bounded_before_the_device():
+    """The 7-wide node test evaluates plane parameters scaled by up to 1e21 (clamped inverse direction x cull scale): coordinates beyond
+    2^38 would overflow them, so such a scene is refused at creation (SOL_EINVAL) instead of losing hits."""
+    from solstrale_amd import CameraConfig, SceneBuilder
+    b = SceneBuilder()
+    m = b.Lambertian(b.SolidColor(.5, .5, .5))
+    world = [b.Sphere((0., 0., 0.), 1., m), b.Sphere((3e11, 0., 0.), 1., m), b.Sphere((0., 5., 0.), 1., b.DiffuseLight(1, 1, 1))]
+    sc = b.finish(b.Bvh(world), CameraConfig(40., 0., (0., 0., 5.), (0., 0., 0.), (0, 1, 0)), (0., 0., 0.), RenderConfig(8, 8, 1))
+    with pytest.raises(DeviceError) as e:
+        DeviceScene(sc)
+    assert e.value.code == _abi.SOL_EINVAL and "2^38" in e.value.msg

@@ -20,7 +20,7 @@ else
   # at most two TA/TD/TCP counters per pass (more: "Request exceeds the capabilities of the hardware")
   for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
              "SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE" \
-             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "TA_BUSY_avr TD_TD_BUSY_sum" "FETCH_SIZE" "WRITE_SIZE"; do   # FETCH_SIZE takes 3 of the 4 TCC counters, WRITE_SIZE 2
+             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "TA_BUSY_avr" "FETCH_SIZE" "WRITE_SIZE"; do   # FETCH_SIZE takes 3 of the 4 TCC counters, WRITE_SIZE 2; TD_TD_BUSY says nothing (profiles/r04_counter_questions.txt)
     if [ -n "$3" ] && [[ "$grp" != *"$3"* ]]; then continue; fi
     name=$(echo $grp | tr ' ' '+')
     echo "== $grp"

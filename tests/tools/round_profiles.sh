@@ -24,6 +24,10 @@ if [[ $part == *b* ]]; then
   run c3_interior --workload c3 --camera-preset interior --no-cpu-baseline
   run c5_closeup --workload c5 --camera-preset closeup --steps 2 --no-cpu-baseline
   run profiling --workload profiling
+  run c3_heterogeneous --workload c3 --mesh-preset heterogeneous --no-cpu-baseline          # the STRESS mesh, default tree (pre-split + reinsertion)
+  run c3_heterogeneous_interior --workload c3 --mesh-preset heterogeneous --camera-preset interior --no-cpu-baseline
+  SOL_SPLIT=0 SOL_REINSERT=0 run c3_heterogeneous_r03tree --workload c3 --mesh-preset heterogeneous --no-cpu-baseline --no-pmc   # the same with round 3's builder (A/B base)
+  SOL_SPLIT=0 SOL_REINSERT=0 run c3_r03tree --workload c3 --no-cpu-baseline --no-pmc
   for f in gpurun_out/${tag}_*_bench.json; do python -c "
 import json
 d = json.load(open('$f'))

@@ -78,6 +78,6 @@ if __name__ == "__main__":
     rc = RenderConfig(1920, 1080, spp)
     make = {"c2": lambda: scenes.cornell_spheres(rc), "c3": lambda: scenes.sponza_like(rc), "c3h": lambda: scenes.sponza_like(rc, mesh="heterogeneous"),
             "c3hi": lambda: scenes.sponza_like(rc, mesh="heterogeneous", camera="interior"), "c3i": lambda: scenes.sponza_like(rc, camera="interior"),
-            "c5": lambda: scenes.statue_like(rc), "test": lambda: scenes.create_test_scene(RenderConfig(800, 400, spp))}
+            "c5": lambda: scenes.statue_like(rc), "c1x": lambda: scenes.cornell_box(rc), "test": lambda: scenes.create_test_scene(RenderConfig(800, 400, spp))}
     for w in which:
         one(w, make[w](), spp, budgets, slacks, check, reinserts, strides)
