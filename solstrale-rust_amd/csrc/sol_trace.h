@@ -17,9 +17,6 @@
 // medium, whose interval includes negative t, walk the reference-shaped 2-wide tree (DNode).
 
 #define REF_DONE 0xFFFFFFFFu
-#ifndef SOL_FAST_INV
-#define SOL_FAST_INV 0
-#endif
 #define SOL_INV_CLAMP 1e18f  // |1 / direction| as the 7-wide node test sees it (wide_node_test: why 1e18)
 #define ALMOST_ZERO_F 1e-8f  // src/geo/vec3.rs:21
 #define RAY_MIN_F 0.001f     // RAY_INTERVAL.min (src/util/interval.rs:25-28)
@@ -246,15 +243,7 @@ struct Trav {
 template <bool WIDE>
 DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, float bxmin, float bxmax, float bymin,
                     float bymax, float bzmin, float bzmax, int sp_base) {
-#if SOL_FAST_INV
-  // (A/B) a 7-wide search only CULLS with the inverse direction (wide_node_test: boxes with three pads of margin): v_rcp_f32, one ulp off
-  // the IEEE quotient, instead of three correctly rounded divisions (~10 instructions each); the 2-wide boundary search, whose
-  // box sequence is part of the result, keeps Ray::new's
-  t.o = o; t.d = d;
-  t.inv = WIDE ? mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)) : mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-#else
   t.o = o; t.d = d; t.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // Ray::new (geo/mod.rs:277-285)
-#endif
   t.tmin = tmin;
   t.h.t = tmax;
   t.h.ref = SOL_MAKE_REF(SOL_REF_NONE, 0);
@@ -272,7 +261,7 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
   // which is false (the reference returns None the same way, after visiting every box - Aabb::hit ignores NaN). Such rays
   // occur a few times per 10^8 samples; without this exit one lane walks the whole tree and tests every primitive.
   if (isnan(d.x) || isnan(d.y) || isnan(d.z) || isnan(o.x) || isnan(o.y) || isnan(o.z)) { t.cur = REF_DONE; return; }
-  if ((WIDE && !SOL_FAST_INV) || (!WIDE && SOL_REF_KIND(root) == SOL_REF_NODE)) {
+  if (WIDE || SOL_REF_KIND(root) == SOL_REF_NODE) {
     float te;
     if (!slab(bxmin, bxmax, bymin, bymax, bzmin, bzmax, o, t.inv, __builtin_signbitf(t.inv.x), __builtin_signbitf(t.inv.y),
               __builtin_signbitf(t.inv.z), te))
