@@ -16,6 +16,7 @@ def scene_of(name, spp, w, h):
     from solstrale_amd import RenderConfig, scenes
     rc = RenderConfig(w, h, spp)
     return {"c1": scenes.cornell_box, "c2": scenes.cornell_spheres, "c3": scenes.sponza_like,
+            "c3h": lambda rc: scenes.sponza_like(rc, mesh="heterogeneous"), "c5": scenes.statue_like,
             "test": scenes.create_test_scene}[name](rc)
 
 
