@@ -93,9 +93,11 @@ def parse_args():
     ap.add_argument("--light", default="", help="with --obj: qx,qy,qz,ux,uy,uz,vx,vy,vz[,r,g,b] Quad light (corner, two edges)")
     ap.add_argument("--hdri", action="store_true", help="c5 only: add the procedural HDR environment map (EXTENSION: the reference has no "
                                                         "environment lights; reported separately from the plain c5 line)")
-    ap.add_argument("--partition", default="balanced", choices=["balanced", "modulo"],
-                    help="N>1: which rank owns an 8x8 block - 'balanced' (default): dealt out by the blocks' cost in the creation probe; "
-                         "'modulo': block b -> rank b mod N")
+    ap.add_argument("--partition", default="modulo", choices=["balanced", "modulo"],
+                    help="N>1: which rank owns an 8x8 block - 'modulo' (default): block b -> rank b mod N; 'balanced': dealt out by the "
+                         "blocks' cost in the creation probe (one-GPU estimate at 8 ranks: 7.78x instead of 7.74x). The table path has run "
+                         "through sol_gather over the test transport only; it becomes the default once a real multi-GPU run has passed its "
+                         "frame check (ADVICE r03)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic = null, no roofline_valu)")

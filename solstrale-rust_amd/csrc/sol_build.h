@@ -29,6 +29,7 @@ struct SolSplitOptions {
   bool want_boxes = false;  // hand the references' boxes back (sol_world_tree_check)
   // Reinsertion rounds after the clustering (sol_build.hip, step 2b): every `stride`-th node looks for a better place in each round
   // (stride 1: all of them).
+  float node_cost = 2.5f;  // collapse: what a wide-node visit costs against a primitive test
   int reinsertion_rounds = 8;
   int reinsertion_stride = 1;
   bool verbose = false;

@@ -46,7 +46,7 @@ namespace {
 constexpr int BT = 256;          // threads per block
 constexpr int PLOC_R_MAX = 64;   // neighbours searched to each side: at most (LDS window); default 16 (SOL_PLOC_R)
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr float NODE_COST = 2.5f, PRIM_COST = 1.0f;  // as WideBuilder (sol_tree.h)
+constexpr float PRIM_COST = 1.0f;  // as WideBuilder (sol_tree.h); the cost of a wide node is SolSplitOptions::node_cost (2.5)
 constexpr int MAXC = SOL_WIDE_CHILDREN;
 
 struct Dp {
@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(BT) k_validate(uint32_t n_nodes, uint32_t n_le
 // most i child slots of its parent.
 __global__ void __launch_bounds__(BT) k_collapse_cost(uint32_t n_leaves, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left,
                                                        const uint32_t* __restrict__ right, const float* __restrict__ nbox, uint32_t* __restrict__ arrived,
-                                                       Dp* __restrict__ dp) {
+                                                       Dp* __restrict__ dp, float NODE_COST) {
   const uint32_t i = blockIdx.x * BT + threadIdx.x;
   if (i >= n_leaves) return;
   {
@@ -1080,7 +1080,7 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n_in, const
     if (h_bad[0] || h_bad[1]) { err = "device tree build: reinsertion left " + std::to_string(h_bad[0]) + " broken links and " + std::to_string(h_bad[1]) + " wrong boxes"; return false; }
   }
   // ---- 3. collapse costs ----
-  hipLaunchKernelGGL(k_collapse_cost, dim3(nb), dim3(BT), 0, stream, n, parent, left, right, nbox, arrived, dp);
+  hipLaunchKernelGGL(k_collapse_cost, dim3(nb), dim3(BT), 0, stream, n, parent, left, right, nbox, arrived, dp, split.node_cost);
   B_LAUNCHED(k_collapse_cost);
   B_TRY(hipStreamSynchronize(stream));
   // ---- 4. emission, level by level ----

@@ -113,6 +113,7 @@ static SolSplitOptions split_options(const SolDevOverrides& ovr, const SolCreate
   if (opt && opt->reinsertion_rounds != 0) sp.reinsertion_rounds = std::max(0, opt->reinsertion_rounds);  // (0: the default, 8 rounds)
   if (ovr.reinsert_rounds >= 0) sp.reinsertion_rounds = ovr.reinsert_rounds;                               // SOL_REINSERT (rounds; 0 = off)
   if (ovr.reinsert_stride > 0) sp.reinsertion_stride = ovr.reinsert_stride;                                // SOL_REINSERT_STRIDE
+  sp.node_cost = (float)ovr.node_cost;  // (SOL_NODE_COST; 2.5)
   sp.verbose = ovr.verbose;
   return sp;
 }
