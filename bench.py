@@ -540,7 +540,9 @@ def worker(args):
             "world_tree": {"builder": tree_info["tree_name"], "presplit_extra_references": tree_info["split_references"],
                            "presplit_triangles": tree_info["split_triangles"], "presplit_box_area_ratio": round(tree_info["split_area_ratio"], 4),
                            "reinsertion_moves": tree_info["reinsertion_moves"], "reinsertion_area_ratio": round(tree_info["reinsertion_area_ratio"], 4),
-                           "note": "pre-splitting is kept only when it shrinks the summed box area of the primitives below 0.85 (regular meshes stay unsplit)"},
+                           "strict_triangles": tree_info["strict_triangles"],
+                           "note": "pre-splitting is kept only when it shrinks the summed box area of the primitives below 0.85 (regular meshes stay unsplit); "
+                                   "strict_triangles: the scene has needle triangles (aspect >= 32:1) - fatter box pad and the triangle consistency rule of the fp32 contract"},
         }
         if world > 1:
             out["rccl_ranks"] = rccl_ranks

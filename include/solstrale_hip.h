@@ -179,6 +179,30 @@ typedef struct SolSceneDesc {
   double env_scale;
 } SolSceneDesc;
 
+/* fp32 arithmetic contract, needle triangles. fp32 Moller-Trumbore (src/hittable/triangle.rs:119-140 in single
+ * precision) is ill-conditioned for triangles of extreme aspect: it accepts rays that pass hundreds of box pads beside the triangle,
+ * and whether such a phantom is seen would depend on which boxes a traversal tested. A scene HAS NEEDLES when some triangle's
+ * longest edge squared is at least 2 * 32 times its area (aspect >= 32:1). For such scenes the fp32 contract - the device and the
+ * oracle's float instantiation alike; in f64 nothing changes - (i) pads every box by S * 2^-14 instead of S * 2^-20 and (ii)
+ * counts a triangle hit only if the ray's point o + t*d and the triangle's point v0 + u*e1 + v*e2 agree within half a pad in
+ * every coordinate: an accepted hit then lies inside every box around its part of the triangle, whatever the tree. Both sides decide
+ * with THIS function. */
+#define SOL_NEEDLE_ASPECT 32.0
+static inline int sol_scene_has_needles(const SolSceneDesc* d) {
+  uint32_t i;
+  for (i = 0; i < d->n_triangles; ++i) {
+    const SolTriangle* t = &d->triangles[i];
+    const double a[3] = {t->v0v1[0], t->v0v1[1], t->v0v1[2]}, b[3] = {t->v0v2[0], t->v0v2[1], t->v0v2[2]};
+    const double c[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    double l2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    const double lb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2], lc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    if (lb > l2) l2 = lb;
+    if (lc > l2) l2 = lc;
+    if (!(l2 < 2.0 * SOL_NEEDLE_ASPECT * t->area)) return 1; /* (a degenerate or NaN triangle counts as a needle) */
+  }
+  return 0;
+}
+
 /* Counters of the last instrumented render (sol_render_counted); zero otherwise. Definitions are the
  * ones SURVEY.md 8d / DESIGN.md use for algorithmic bytes. */
 typedef struct SolStats {
@@ -250,6 +274,7 @@ typedef struct SolSceneInfo {
                                 probe's block costs exist AND world > 1); 0: block b belongs to rank b % world                  */
   uint32_t partition_crc;    /* checksum of the block -> (rank, local block) mapping in force: equal on every rank of a job, or the
                                 ranks render different partitions (each derives the table from its own probe)                     */
+  uint32_t strict_triangles; /* 1: the scene has needle triangles (sol_scene_has_needles): fatter box pad, triangle consistency rule  */
 } SolSceneInfo;
 int sol_scene_info(const SolScene* scene, SolSceneInfo* out);
 

@@ -231,6 +231,7 @@ int sol_scene_info(const SolScene* s, SolSceneInfo* out) {
   r.reinsertion_area_ratio = s->reinsertion_area_ratio;
   r.partition_table = s->partition_table;
   r.partition_crc = s->partition_crc;
+  r.strict_triangles = s->strict_triangles ? 1u : 0u;
   std::memcpy(out, &r, r.size);
   return SOL_OK;
 }

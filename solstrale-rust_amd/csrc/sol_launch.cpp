@@ -40,11 +40,12 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   // A/B runs: they raise the search's lane occupancy (0.45 -> 0.67-0.73) but pay for it in state traffic, refill stalls and
   // per-round tails (MI355X, C3, 128 spp: v1 997, v2 905, v3 684 Msamples/s when they were last compared).
   int version = s->kernel_version ? s->kernel_version : 1;
+  if (version != 1 && s->strict_triangles) return sol_fail(SOL_EINVAL, "kernel variant %d does not implement the consistency rule of scenes with needle triangles", version);
 #ifndef SOL_AB_KERNELS
   if (version != 1) return sol_fail(SOL_EINVAL, "kernel variant %d exists only in -DSOL_AB_KERNELS builds of the library", version);
-  int bpc = sol_render_blocks_per_cu(version, count, s->has_medium);
+  int bpc = sol_render_blocks_per_cu(version, count, s->has_medium, s->strict_triangles);
 #else
-  int bpc = version == 3 ? sol_wf_trace_blocks_per_cu(count, s->has_medium) : sol_render_blocks_per_cu(version, count, s->has_medium);
+  int bpc = version == 3 ? sol_wf_trace_blocks_per_cu(count, s->has_medium) : sol_render_blocks_per_cu(version, count, s->has_medium, s->strict_triangles);
 #endif
   if (s->max_bpc > 0) bpc = std::max(1, std::min(bpc, s->max_bpc));  // SOL_OPT_MAX_BLOCKS_PER_CU
   uint32_t grid = (uint32_t)(s->n_cu * bpc);

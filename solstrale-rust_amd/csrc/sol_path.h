@@ -68,7 +68,7 @@ DEV f3 env_color(const DevScene& S, f3 dir) {
 
 // Processes the result `h` of world.hit(ray) for the path `p`. Returns true when the sample is finished, with its colour
 // (get_attenuated_color applied) in `contrib`; returns false when the path continues with the new ray in p.o / p.d.
-template <bool COUNT>
+template <bool COUNT, bool STRICT = false>
 DEV bool shade_vertex(const DevScene& S, Path& p, const Hit& h, f3& contrib, Counters& cnt) {
   bool terminal = true;
   f3 x = mk3(S.bgx, S.bgy, S.bgz);  // miss: background (src/renderer/mod.rs:197-204)
@@ -85,7 +85,7 @@ DEV bool shade_vertex(const DevScene& S, Path& p, const Hit& h, f3& contrib, Cou
       if (S.shader == SOL_SHADER_NORMAL) {  // shader.rs:165-172
         x = sf.normal;
       } else {  // Albedo (shader.rs:141-151), Simple (shader.rs:192-214)
-        scatter<COUNT>(S, p.d, sf, p.rng, sc, cnt);
+        scatter<COUNT, STRICT>(S, p.d, sf, p.rng, sc, cnt);
         x = sc.color;
         if (S.shader == SOL_SHADER_SIMPLE && sc.type != SCATTER_EMISSION)
           x = sc.color * (dot3(sf.normal, mk3(1.f, 1.f, -1.f)) * 0.5f + 0.75f);
@@ -94,7 +94,7 @@ DEV bool shade_vertex(const DevScene& S, Path& p, const Hit& h, f3& contrib, Cou
       x = mk3(0.f, 0.f, 0.f);
     } else {
       const float total = sf.t + p.acc_len;  // shader.rs:74
-      scatter<COUNT>(S, p.d, sf, p.rng, sc, cnt);
+      scatter<COUNT, STRICT>(S, p.d, sf, p.rng, sc, cnt);
       if (sc.type == SCATTER_EMISSION) {  // shader.rs:78-84
         x = sc.color; has_af = sc.has_af; af = sc.af; path_len = total;
       } else {

@@ -17,7 +17,9 @@
 
 // SPILL = false: built for scenes whose searches fit the LDS stack (sol_api.cpp picks it by the tree's depth): every stack access
 // is a plain LDS access, the spill branches and their waits fold away.
-template <bool COUNT, bool MEDIUM, bool SPILL>
+// STRICT = true: built for scenes with needle triangles (include/solstrale_hip.h, sol_scene_has_needles): the closest hit of a finished
+// search must pass the triangle consistency rule before it is shaded, or the lane searches the same ray again for what lies behind it.
+template <bool COUNT, bool MEDIUM, bool SPILL, bool STRICT>
 __global__ void __launch_bounds__(SOL_WG, SOL_V1_MIN_WAVES)  // 4 waves per SIMD: the 32 KiB LDS stack allows 5 workgroups per CU, 128 VGPRs 4
 sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* __restrict__ acc, float* __restrict__ partial,
                   uint32_t* __restrict__ work_counter, uint32_t* __restrict__ spill, DevCounters* __restrict__ dcnt) {
@@ -56,6 +58,8 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
 
   for (;;) {
     // ---- lanes whose search is over: shade the vertex, then start the next ray of the path / sample / item ----
+    // (STRICT) a finished search whose closest hit is a triangle the consistency rule refuses: the lane searches again, behind that hit
+    if (STRICT && t.cur == REF_DONE && in_flight) trav_accept_or_restart(S, t, st);
     if (t.cur == REF_DONE) {
       if (in_flight) {
         in_flight = false;
@@ -63,7 +67,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         p.o = t.o; p.d = t.d;  // (the ray lives in the search state while it is traced)
         f3 c;
         if (COUNT && p.depth == 0u && SOL_REF_KIND(t.h.ref) != SOL_REF_NONE) cnt.primary_hits++;
-        if (shade_vertex<COUNT>(S, p, t.h, c, cnt)) {
+        if (shade_vertex<COUNT, STRICT>(S, p, t.h, c, cnt)) {
           if (COUNT) count_path(cnt, p.depth + 1u);  // (depth counts the scatterings before this vertex)
           sum = sum + c;  // add_row_data (src/renderer/mod.rs:361-365): sums, not means
           alive = false;
@@ -144,7 +148,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
       if (am == 0ull) break;
       const unsigned long long live = sol_ballot(true);
       if (am != live && (uint32_t)__popcll(am) * 64u < P.switch_below * (uint32_t)__popcll(live)) break;
-      trav_step_wave<COUNT, MEDIUM>(S, t, act, st, p.rng, p.depth, cnt);
+      trav_step_wave<COUNT, MEDIUM, STRICT>(S, t, act, st, p.rng, p.depth, cnt);
     }
 #if SOL_LOOP_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -177,7 +181,7 @@ hipError_t sol_launch_stage_resolve(const DevScene* dS, const RenderParams& P, f
 
 // Diagnostic: one path (pixel, sample) on one lane, every ray and its closest hit recorded: 12 floats per ray
 // (origin, direction, t, ref bits, dfs bits, depth, 0, 0), then a terminator row (colour in the first 3 floats, -1 in the 4th).
-template <bool MEDIUM>
+template <bool MEDIUM, bool STRICT>
 __global__ void __launch_bounds__(SOL_WG)
 sol_debug_path_kernel(const DevScene S, const RenderParams P, uint32_t px, uint32_t py, uint32_t s, uint32_t* __restrict__ spill,
                       float* __restrict__ out, uint32_t max_rows) {
@@ -204,7 +208,7 @@ sol_debug_path_kernel(const DevScene S, const RenderParams P, uint32_t px, uint3
       row++;
     }
     f3 c;
-    if (shade_vertex<false>(S, p, h, c, cnt)) {
+    if (shade_vertex<false, STRICT>(S, p, h, c, cnt)) {
       float* o = out + (size_t)row * 12;
       o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = -1.0f;
       return;
@@ -213,30 +217,37 @@ sol_debug_path_kernel(const DevScene S, const RenderParams P, uint32_t px, uint3
 }
 hipError_t sol_launch_debug_path(const DevScene& S, const RenderParams& P, uint32_t px, uint32_t py, uint32_t s, uint32_t* spill,
                                  float* out, uint32_t max_rows, bool medium, hipStream_t stream) {
-  if (medium) hipLaunchKernelGGL((sol_debug_path_kernel<true>), dim3(1), dim3(SOL_WG), 0, stream, S, P, px, py, s, spill, out, max_rows);
-  else hipLaunchKernelGGL((sol_debug_path_kernel<false>), dim3(1), dim3(SOL_WG), 0, stream, S, P, px, py, s, spill, out, max_rows);
+#define DEBUG_PATH(M, ST) hipLaunchKernelGGL((sol_debug_path_kernel<M, ST>), dim3(1), dim3(SOL_WG), 0, stream, S, P, px, py, s, spill, out, max_rows)
+  if (S.tri_delta > 0.0f) { if (medium) DEBUG_PATH(true, true); else DEBUG_PATH(false, true); }
+  else { if (medium) DEBUG_PATH(true, false); else DEBUG_PATH(false, false); }
+#undef DEBUG_PATH
   return hipGetLastError();
 }
 
 // ---- launch wrappers (called from sol_launch.cpp) ----
-template <bool COUNT, bool MEDIUM, bool SPILL>
+template <bool COUNT, bool MEDIUM, bool SPILL, bool STRICT>
 static hipError_t launch_v1(const DevScene* dS, const RenderParams& P, float* acc, float* partial, uint32_t* work,
                             uint32_t* spill, DevCounters* cnt, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL((sol_render_kernel<COUNT, MEDIUM, SPILL>), dim3(grid), dim3(SOL_WG), 0, stream, dS, P, acc, partial, work, spill, cnt);
+  hipLaunchKernelGGL((sol_render_kernel<COUNT, MEDIUM, SPILL, STRICT>), dim3(grid), dim3(SOL_WG), 0, stream, dS, P, acc, partial, work, spill, cnt);
   return hipGetLastError();
+}
+template <bool STRICT>
+static hipError_t launch_v1_any(const DevScene* dS, const RenderParams& P, float* acc, float* partial, uint32_t* work, uint32_t* spill, DevCounters* cnt,
+                                uint32_t grid, bool count, bool medium, bool may_spill, hipStream_t stream) {
+  if (count) return medium ? launch_v1<true, true, true, STRICT>(dS, P, acc, partial, work, spill, cnt, grid, stream)
+                           : launch_v1<true, false, true, STRICT>(dS, P, acc, partial, work, spill, cnt, grid, stream);
+  if (may_spill) return medium ? launch_v1<false, true, true, STRICT>(dS, P, acc, partial, work, spill, cnt, grid, stream)
+                               : launch_v1<false, false, true, STRICT>(dS, P, acc, partial, work, spill, cnt, grid, stream);
+  return medium ? launch_v1<false, true, false, STRICT>(dS, P, acc, partial, work, spill, cnt, grid, stream)
+                : launch_v1<false, false, false, STRICT>(dS, P, acc, partial, work, spill, cnt, grid, stream);
 }
 
 hipError_t sol_launch_render(int version, const DevScene& S, const DevScene* dS, const RenderParams& P, float* acc, float* partial, uint32_t* work,
                              uint32_t* spill, void* pool, DevCounters* cnt, uint32_t grid, bool count, bool medium, bool may_spill,
                              hipStream_t stream) {
-  if (version == 1) {
-    if (count) return medium ? launch_v1<true, true, true>(dS, P, acc, partial, work, spill, cnt, grid, stream)
-                             : launch_v1<true, false, true>(dS, P, acc, partial, work, spill, cnt, grid, stream);
-    if (may_spill) return medium ? launch_v1<false, true, true>(dS, P, acc, partial, work, spill, cnt, grid, stream)
-                                 : launch_v1<false, false, true>(dS, P, acc, partial, work, spill, cnt, grid, stream);
-    return medium ? launch_v1<false, true, false>(dS, P, acc, partial, work, spill, cnt, grid, stream)
-                  : launch_v1<false, false, false>(dS, P, acc, partial, work, spill, cnt, grid, stream);
-  }
+  if (version == 1)
+    return S.tri_delta > 0.0f ? launch_v1_any<true>(dS, P, acc, partial, work, spill, cnt, grid, count, medium, may_spill, stream)
+                              : launch_v1_any<false>(dS, P, acc, partial, work, spill, cnt, grid, count, medium, may_spill, stream);
 #ifdef SOL_AB_KERNELS
   return sol_launch_pool(S, P, acc, partial, work, spill, pool, cnt, grid, count, medium, stream);  // (sol_wavefront.hip)
 #else
@@ -250,10 +261,14 @@ static int blocks_per_cu(K kernel) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, SOL_WG, 0) != hipSuccess || n < 1) n = 1;
   return n;
 }
-int sol_render_blocks_per_cu(int version, bool count, bool medium) {
+int sol_render_blocks_per_cu(int version, bool count, bool medium, bool strict) {
   if (version == 1) {  // (the SPILL = false builds need no more registers or LDS than these)
-    if (count) return medium ? blocks_per_cu(sol_render_kernel<true, true, true>) : blocks_per_cu(sol_render_kernel<true, false, true>);
-    return medium ? blocks_per_cu(sol_render_kernel<false, true, true>) : blocks_per_cu(sol_render_kernel<false, false, true>);
+    if (strict) {
+      if (count) return medium ? blocks_per_cu(sol_render_kernel<true, true, true, true>) : blocks_per_cu(sol_render_kernel<true, false, true, true>);
+      return medium ? blocks_per_cu(sol_render_kernel<false, true, true, true>) : blocks_per_cu(sol_render_kernel<false, false, true, true>);
+    }
+    if (count) return medium ? blocks_per_cu(sol_render_kernel<true, true, true, false>) : blocks_per_cu(sol_render_kernel<true, false, true, false>);
+    return medium ? blocks_per_cu(sol_render_kernel<false, true, true, false>) : blocks_per_cu(sol_render_kernel<false, false, true, false>);
   }
 #ifdef SOL_AB_KERNELS
   return sol_pool_blocks_per_cu(count, medium);

@@ -116,6 +116,7 @@ struct SolScene {
   SolStats stats{};
   SolPathStats path_stats{};
   bool has_medium = false;
+  bool strict_triangles = false;  // the scene has needle triangles: the STRICT kernel variants (sol_render.hip)
   uint32_t tree_depth = 0;
   int rank = 0, world = 1;
   uint32_t blocks_x = 0, blocks_y = 0, n_local_blocks = 0;

@@ -108,7 +108,7 @@ DEV f3 transformed_normal(const DevScene& S, int mid, const Surface& sf, Rng& rn
 
 // ---- light sampling (pdf.rs:75-102) ------------------------------------------------------------------------------
 // Hittable::pdf_value of quad (quad.rs:132-143), triangle (triangle.rs:100-112), sphere (sphere.rs:40-56)
-template <bool COUNT>
+template <bool COUNT, bool STRICT = false>
 DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Counters& cnt) {
   const uint32_t kind = SOL_REF_KIND(ref), idx = SOL_REF_INDEX(ref);
   const float inf = __builtin_huge_valf();
@@ -129,6 +129,7 @@ DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Co
     if (COUNT) cnt.triangle_tests++;
     float t, u, v;
     if (!tri_test(T, origin, dir, RAY_MIN_F, inf, t, u, v)) return 0.0f;
+    if (STRICT && !tri_hit_consistent(T, origin, dir, t, u, v, S.tri_delta)) return 0.0f;  // (scenes with needle triangles: sol_trace.h)
     f3 n = mk3(Ts.nx, Ts.ny, Ts.nz);
     if (!(dot3(dir, n) < 0.0f)) n = neg3(n);
     float ds = t * t * len2(dir);
@@ -170,11 +171,11 @@ DEV f3 light_random_direction(const DevScene& S, uint32_t ref, f3 origin, Rng& r
   float zz = sol_sqrt(1.0f - z * z);
   return onb_local(uvw, mk3(c * zz, s * zz, z));
 }
-template <bool COUNT>
+template <bool COUNT, bool STRICT = false>
 DEV float container_pdf_value(const DevScene& S, f3 origin, f3 dir, Counters& cnt) {  // pdf.rs:89-96
   float sum = 0.0f;
-  if (S.n_lights == 1u) return light_pdf_value<COUNT>(S, S.light0, origin, dir, cnt) / 1.0f;  // (x / 1 == x: same value as the loop)
-  for (uint32_t i = 0; i < S.n_lights; ++i) sum += light_pdf_value<COUNT>(S, ldg_u32(S.lights + i), origin, dir, cnt);
+  if (S.n_lights == 1u) return light_pdf_value<COUNT, STRICT>(S, S.light0, origin, dir, cnt) / 1.0f;  // (x / 1 == x: same value as the loop)
+  for (uint32_t i = 0; i < S.n_lights; ++i) sum += light_pdf_value<COUNT, STRICT>(S, ldg_u32(S.lights + i), origin, dir, cnt);
   return sum / (float)S.n_lights;
 }
 DEV f3 container_pdf_generate(const DevScene& S, f3 origin, Rng& rng) {  // pdf.rs:98-101
@@ -214,7 +215,7 @@ struct Scatter {
 
 // Materials::scatter (material/mod.rs:191-207 Lambertian, :239-249 Metal, :279-302 Dielectric, :359-368 DiffuseLight,
 // :396-410 Isotropic, :430-436 Blend)
-template <bool COUNT>
+template <bool COUNT, bool STRICT = false>
 DEV void scatter(const DevScene& S, f3 ray_dir, const Surface& sf, Rng& rng, Scatter& sc, Counters& cnt) {
   DMat m = ldg_rec(S.mats + sf.mat);
   for (int guard = 0; guard < 16 && m.kind == SOL_MAT_BLEND; ++guard) m = ldg_rec(S.mats + (rnd(rng) > m.param ? m.m1 : m.m2));
@@ -229,7 +230,7 @@ DEV void scatter(const DevScene& S, f3 ray_dir, const Surface& sf, Rng& rng, Sca
     else dir = onb_local(uvw, random_cosine_direction(rng));
     f3 udir = unit3(dir);
     float cos_pdf = fmaxf(dot3(udir, uvw.normal) / SOL_PI, 0.0f);                                 // CosinePdf::value
-    float mix = 0.5f * container_pdf_value<COUNT>(S, sf.p, dir, cnt) + 0.5f * cos_pdf;            // mix_value
+    float mix = 0.5f * container_pdf_value<COUNT, STRICT>(S, sf.p, dir, cnt) + 0.5f * cos_pdf;            // mix_value
     float cos_theta = dot3(sf.normal, udir);                                                      // scattering_pdf_value
     float scattering = cos_theta < 0.0f ? 0.0f : cos_theta / SOL_PI;
     sc.dir = dir;
@@ -266,7 +267,7 @@ DEV void scatter(const DevScene& S, f3 ray_dir, const Surface& sf, Rng& rng, Sca
     if (rnd(rng) < 0.5f) dir = container_pdf_generate(S, sf.p, rng);
     else dir = unit3(random_in_unit_sphere(rng));  // SpherePdf::generate (pdf.rs:121-124)
     const float sphere_pdf = (float)(1. / (4. * 3.14159265358979323846));
-    float mix = 0.5f * container_pdf_value<COUNT>(S, sf.p, dir, cnt) + 0.5f * sphere_pdf;
+    float mix = 0.5f * container_pdf_value<COUNT, STRICT>(S, sf.p, dir, cnt) + 0.5f * sphere_pdf;
     sc.dir = dir;
     sc.probability = sphere_pdf / mix;
   }

@@ -200,6 +200,14 @@ DEV bool sphere_test(const DSphere& S, f3 o, f3 d, float tmin, float tmax, float
 DEV bool better(float t, uint32_t dfs, const Hit& h) {
   return t < h.t || (t == h.t && (SOL_REF_KIND(h.ref) == SOL_REF_NONE || dfs > h.dfs));
 }
+// fp32 contract, scenes with needle triangles (include/solstrale_hip.h): the ray's point o + t*d and the triangle's point
+// v0 + u*e1 + v*e2 of a hit agree within `delta` (half a box pad) in every coordinate - the operation order of oracle.cpp, hit_triangle.
+DEV bool tri_hit_consistent(const DTri& T, f3 o, f3 d, float t, float u, float v, float delta) {
+  const f3 p = o + d * t;
+  const f3 q = mk3(T.v0x, T.v0y, T.v0z) + mk3(T.e1x, T.e1y, T.e1z) * u + mk3(T.e2x, T.e2y, T.e2z) * v;
+  const f3 dl = p - q;
+  return fabsf(dl.x) <= delta && fabsf(dl.y) <= delta && fabsf(dl.z) <= delta;
+}
 
 // State of one closest-hit search.
 //
@@ -236,6 +244,10 @@ struct Trav {
   uint32_t g0, g1, pg, oct;  // (7-wide searches only; oct = the ray's octant, sign bits of the direction as x<<2 | y<<1 | z)
   Hit h;
   MedSearch m;               // (MEDIUM kernels only; dead otherwise)
+  // (STRICT kernels only: scenes with needle triangles) a search that follows a closest hit the consistency rule refused looks only
+  // for triangle hits BEHIND that one in the order of `better`: t > bt, or t == bt with an earlier dfs index
+  float bt;
+  uint32_t bdfs;
 };
 
 // Starts a search of `root` over [tmin, tmax]; (bxmin..bzmax) is root's own box, tested first when root is a node
@@ -256,6 +268,8 @@ DEV void trav_begin(Trav& t, f3 o, f3 d, float tmin, float tmax, uint32_t root, 
   t.g1 = 0u;
   t.pg = 0u;
   t.m.phase = 0u;
+  t.bt = -__builtin_huge_valf();  // (a search behind a refused hit sets its bound after this call)
+  t.bdfs = 0u;
   t.oct = (__builtin_signbitf(t.inv.x) ? 4u : 0u) | (__builtin_signbitf(t.inv.y) ? 2u : 0u) | (__builtin_signbitf(t.inv.z) ? 1u : 0u);
   // A ray with a NaN in its origin or direction cannot hit anything: every primitive test ends in a comparison with NaN,
   // which is false (the reference returns None the same way, after visiting every box - Aabb::hit ignores NaN). Such rays
@@ -372,8 +386,11 @@ DEV void wide_node_test(const Stack& st, Trav& t, uint32_t oct, float4 h, uint4 
 
 // Tests primitive `idx` of kind `kind` against the search's interval [tmin, best t] and keeps it when it is the better hit
 // (smaller t; among equal t the later one in depth-first leaf order, bvh.rs:172-178).
-template <bool COUNT>
-DEV void triangle_prim_test(Trav& t, const Stack& st, uint32_t idx, Counters& cnt) {
+// STRICT (scenes with needle triangles): 0 off; 1 = a world search - hits not behind the search's bound (t.bt, t.bdfs) are skipped, the
+// consistency of the CLOSEST hit is checked by the caller when the search is over (sol_render.hip); 2 = a boundary search of a constant
+// medium, whose every candidate is checked here (delta = DevScene::tri_delta, 0: the scene has no needles).
+template <bool COUNT, int STRICT = 0>
+DEV void triangle_prim_test(Trav& t, const Stack& st, uint32_t idx, Counters& cnt, float delta = 0.0f) {
   const float4* tp = reinterpret_cast<const float4*>(st.tris + idx);
 #if SOL_FETCH_PRIO >= 10
   __builtin_amdgcn_s_setprio(SOL_FETCH_PRIO / 10);
@@ -388,6 +405,8 @@ DEV void triangle_prim_test(Trav& t, const Stack& st, uint32_t idx, Counters& cn
   if (COUNT) cnt.triangle_tests++;
   float tt, u, v;
   if (tri_test(T, t.o, t.d, t.tmin, t.h.t, tt, u, v) && better(tt, dfs, t.h)) {
+    if (STRICT == 1 && (tt < t.bt || (tt == t.bt && dfs >= t.bdfs))) return;
+    if (STRICT == 2 && delta > 0.0f && !tri_hit_consistent(T, t.o, t.d, tt, u, v, delta)) return;
     t.h.t = tt; t.h.ref = SOL_MAKE_REF(SOL_REF_TRIANGLE, idx); t.h.dfs = dfs; t.h.u = u; t.h.v = v;
   }
 }
@@ -410,10 +429,10 @@ DEV void quad_prim_test(const DevScene& S, Trav& t, uint32_t idx, Counters& cnt)
   }
 }
 // (a constant medium is not tested here: a world search starts its boundary searches as a sub-state, medium_begin)
-template <bool COUNT>
+template <bool COUNT, int STRICT = 0>
 DEV void prim_test(const DevScene& S, Trav& t, const Stack& st, uint32_t kind, uint32_t idx, Counters& cnt) {
   if (kind == SOL_REF_TRIANGLE) {
-    triangle_prim_test<COUNT>(t, st, idx, cnt);
+    triangle_prim_test<COUNT, STRICT>(t, st, idx, cnt, S.tri_delta);
   } else if (kind == SOL_REF_SPHERE) {
     sphere_prim_test<COUNT>(S, t, idx, cnt);
   } else if (kind == SOL_REF_QUAD) {
@@ -495,7 +514,7 @@ DEV void boundary_step(const DevScene& S, Trav& t, const Stack& st, Counters& cn
     kind = SOL_REF_KIND(cur);
   }
   if (cur == REF_DONE || kind == SOL_REF_NODE) { t.cur = cur; return; }
-  prim_test<COUNT>(S, t, st, kind, SOL_REF_INDEX(cur), cnt);
+  prim_test<COUNT, 2>(S, t, st, kind, SOL_REF_INDEX(cur), cnt);  // (2: a boundary of needle triangles checks every candidate)
   t.cur = (t.sp == t.sp_base) ? REF_DONE : stack_pop(st, t.sp);
 }
 
@@ -524,6 +543,7 @@ DEV void medium_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng
     Trav b;
     b.o = t.o; b.d = t.d; b.inv = t.m.inv; b.tmin = t.m.tmin; b.cur = t.m.cur; b.sp = t.m.sp; b.sp_base = t.sp;
     b.h.t = t.m.t; b.h.ref = t.m.ref; b.h.dfs = t.m.dfs; b.h.u = b.h.v = 0.0f;
+    b.bt = 0.0f; b.bdfs = 0u;
     boundary_step<COUNT>(S, b, st, cnt);
     t.m.cur = b.cur; t.m.sp = b.sp; t.m.t = b.h.t; t.m.ref = b.h.ref; t.m.dfs = b.h.dfs;
   }
@@ -562,7 +582,7 @@ DEV void medium_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng
 // visits per step, while a wave whose lanes are spread over nodes and primitives pays for both parts anyway. The votes on the
 // step's shape (does any lane hold primitives? are they postponed?) are taken by the whole wave once, not inside the divergent
 // region of the searching lanes (MI355X, 64 spp, ms: C3 69.57 -> 68.85, C2 44.0 -> 43.45, C1 10.37 -> 10.30).
-template <bool COUNT, bool MEDIUM>
+template <bool COUNT, bool MEDIUM, bool STRICT = false>
 DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
   // (MEDIUM) a lane inside a medium test rests its world search: no node visit, no primitive of its group, until the test is over
   const bool world = !MEDIUM || t.m.phase == 0u;
@@ -597,7 +617,7 @@ DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, c
     // Triangle leaves go straight to their test: through prim_test's chain (leaf kind -> reference kind -> compare tree) every
     // test had nine more vector instructions in front of it (C3 74.8 -> 73.3 ms per 64 spp); the other kinds keep the chain.
     if (lkind == SOL_LEAF_TRIANGLES) {
-      triangle_prim_test<COUNT>(t, st, idx, cnt);
+      triangle_prim_test<COUNT, STRICT ? 1 : 0>(t, st, idx, cnt);
     } else {
       uint32_t kind = lkind == SOL_LEAF_SPHERES ? SOL_REF_SPHERE : SOL_REF_QUAD;
       if (lkind == SOL_LEAF_REFS) {  // mixed node: the reference is listed
@@ -606,7 +626,7 @@ DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, c
         idx = SOL_REF_INDEX(r);
       }
       if (MEDIUM && kind == SOL_REF_MEDIUM) medium_begin(S, t, idx);
-      else prim_test<COUNT>(S, t, st, kind, idx, cnt);
+      else prim_test<COUNT, STRICT ? 1 : 0>(S, t, st, kind, idx, cnt);
     }
     if ((t.pg >> 24) == 0u && (t.g0 >> 24) == 0u && t.sp == t.sp_base && !(MEDIUM && t.m.phase != 0u)) t.cur = REF_DONE;
   }
@@ -618,20 +638,38 @@ DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, c
 
 // The same step for callers outside the product kernel's loop (the diagnostic path kernel, the A/B wavefront kernels): the lanes
 // that call it are the wave as far as its votes are concerned.
-template <bool COUNT, bool MEDIUM>
+template <bool COUNT, bool MEDIUM, bool STRICT = false>
 DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
-  trav_step_wave<COUNT, MEDIUM>(S, t, true, st, rng, depth, cnt);
+  trav_step_wave<COUNT, MEDIUM, STRICT>(S, t, true, st, rng, depth, cnt);
 }
 
-// Run-to-completion form of a world search.
+// Scenes with needle triangles: is the closest hit of a finished search acceptable? A triangle hit must pass the consistency rule; if
+// it does not, `t` is set up to search the same ray again for what lies BEHIND the refused hit (false). Spheres, quads and media pass.
+DEV bool trav_accept_or_restart(const DevScene& S, Trav& t, const Stack& st) {
+  if (SOL_REF_KIND(t.h.ref) != SOL_REF_TRIANGLE) return true;
+  const DTri T = ldg_rec(st.tris + SOL_REF_INDEX(t.h.ref));
+  if (tri_hit_consistent(T, t.o, t.d, t.h.t, t.h.u, t.h.v, S.tri_delta)) return true;
+  const float bt = t.h.t;
+  const uint32_t bdfs = t.h.dfs;
+  trav_begin<true>(t, t.o, t.d, RAY_MIN_F, __builtin_huge_valf(), S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
+  t.bt = bt;
+  t.bdfs = bdfs;
+  return false;
+}
+
+// Run-to-completion form of a world search (strict: the scene has needle triangles - the run-time form of the kernels' STRICT).
 template <bool COUNT, bool MEDIUM>
 DEV void closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, Hit& h, const Stack& st, int sp_base, const Rng& rng,
                      uint32_t depth, Counters& cnt) {
   Trav t;
   trav_begin<true>(t, o, d, tmin, tmax, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, sp_base);
-  while (t.cur != REF_DONE) trav_step<COUNT, MEDIUM>(S, t, st, rng, depth, cnt);
+  for (int guard = 0; guard < 64; ++guard) {
+    while (t.cur != REF_DONE) trav_step<COUNT, MEDIUM, true>(S, t, st, rng, depth, cnt);
+    if (!(S.tri_delta > 0.0f) || trav_accept_or_restart(S, t, st)) break;
+  }
   h = t.h;
 }
+
 // The random unit normal of a medium hit (same sub-stream, draws 1..).
 DEV f3 medium_normal(const Rng& rng, uint32_t midx, uint32_t depth) {
   uint32_t c = 0x40000000u + (((depth & 0x3FFu) << 20) | ((midx & 0xFFFu) << 8)) + 1u;

@@ -141,7 +141,7 @@ class SolSceneInfo(C.Structure):
                 ("tree_fallback", C.c_uint32), ("tree_name", C.c_char * 32), ("tree_note", C.c_char * 192),
                 ("split_references", C.c_uint32), ("split_triangles", C.c_uint32), ("split_area_ratio", C.c_float),
                 ("reinsertion_moves", C.c_uint32), ("reinsertion_area_ratio", C.c_float),
-                ("partition_table", C.c_uint32), ("partition_crc", C.c_uint32)]
+                ("partition_table", C.c_uint32), ("partition_crc", C.c_uint32), ("strict_triangles", C.c_uint32)]
 
 
 class SolPathStats(C.Structure):

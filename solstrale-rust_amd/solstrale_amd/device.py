@@ -116,7 +116,7 @@ class DeviceScene:
                 "tree_fallback": bool(r.tree_fallback), "tree_name": r.tree_name.decode(), "tree_note": r.tree_note.decode(),
                 "split_references": int(r.split_references), "split_triangles": int(r.split_triangles), "split_area_ratio": float(r.split_area_ratio),
                 "reinsertion_moves": int(r.reinsertion_moves), "reinsertion_area_ratio": float(r.reinsertion_area_ratio),
-                "partition_table": int(r.partition_table), "partition_crc": int(r.partition_crc)}
+                "partition_table": int(r.partition_table), "partition_crc": int(r.partition_crc), "strict_triangles": bool(r.strict_triangles)}
 
     def path_stats(self):
         """sol_path_stats of the last counted render: primary hit fraction and the path-length histogram (shares of the samples)."""

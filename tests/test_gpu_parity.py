@@ -71,6 +71,40 @@ def test_c3_heterogeneous_mesh_crop():
     assert_parity(sc, 8, rect=(1000, 300, 1128, 428))   # under the gallery: capitals, rails, balusters
 
 
+def test_needle_triangles_do_not_make_the_tree_matter(monkeypatch):
+    """fp32 Moller-Trumbore (triangle.rs:119-140 in single precision) on triangles of aspect 300:1 - the tie rods of the heterogeneous
+    atrium - accepts rays that miss the triangle by hundreds of round-3 box pads, and whether such a phantom was seen depended on the
+    boxes that led to the test: at 1080p, pixel (1350, 137) sample 8 - a "hit" 1e-4 beyond a rod's tip, inside the device's
+    quantised leaf box and outside the oracle's exact one - and pixel (1895, 966) sample 26 - a ray skimming a rod's plane, seen by
+    the unsplit tree and the oracle, not by the pre-split tree. With the needle rule of the fp32 contract (include/solstrale_hip.h:
+    fatter pad + the consistency of the ray's and the triangle's point of a hit, in the oracle's float instantiation and on the
+    device) every tree and the oracle agree: those two paths ray by ray, the pre-split and the unsplit frame bit for bit at the size
+    where one pixel used to differ, and a full frame against the oracle."""
+    sc = scenes.sponza_like(RenderConfig(1920, 1080, 64), mesh="heterogeneous")
+    with DeviceScene(sc) as ds:
+        assert ds.info()["strict_triangles"] and ds.info()["split_references"] > 10000
+        for (x, y, s_) in ((1350, 137, 8), (1895, 966, 26), (578, 56, 468), (1350, 137, 504)):
+            rows, colour = ds.debug_path(x, y, s_, pu.SEED)
+            orows, ocolour = orc.debug_path(sc, x, y, s_, pu.SEED, real=orc.ORC_F32)
+            assert len(rows) == len(orows) and np.abs(colour - ocolour).max() <= 1e-6 * max(1e-3, float(np.abs(ocolour).max())), (x, y, s_, colour, ocolour)
+            for r, o in zip(rows, orows):
+                assert r[6] == o[6] or abs(r[6] - o[6]) <= 1e-6 * abs(o[6]), (x, y, s_, r[:8], o[:8])  # the same hit parameter, ray by ray
+        ds.render(0, 64, pu.SEED)
+        split = ds.read()
+    monkeypatch.setenv("SOL_SPLIT", "0")
+    with DeviceScene(sc) as ds:
+        assert ds.info()["strict_triangles"] and ds.info()["split_references"] == 0
+        ds.render(0, 64, pu.SEED)
+        plain = ds.read()
+    monkeypatch.delenv("SOL_SPLIT")
+    assert (split == plain).all(), int((split != plain).any(axis=-1).sum())
+    small = scenes.sponza_like(RenderConfig(480, 270, 16), mesh="heterogeneous")
+    assert_parity(small, 16)  # the whole frame
+    # scenes without needles keep the round-3 contract (no rule, the thin pad)
+    with DeviceScene(scenes.sponza_like(RenderConfig(64, 64, 1))) as ds:
+        assert not ds.info()["strict_triangles"]
+
+
 @pytest.mark.parametrize("env", [{"SOL_BVH": "ref"}, {"SOL_BVH": "sah"}, {"SOL_SWITCH": "0"}, {"SOL_SWITCH": "40"},
                                  {"SOL_BVH": "sah", "SOL_SLOTS": "octant"}, {"SOL_SPLIT": "0"}, {"SOL_SPLIT": "100", "SOL_SPLIT_SLACK": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
