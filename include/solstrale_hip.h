@@ -183,8 +183,8 @@ typedef struct SolSceneDesc {
  * precision) is ill-conditioned for triangles of extreme aspect: it accepts rays that pass hundreds of box pads beside the triangle,
  * and whether such a phantom is seen would depend on which boxes a traversal tested. A scene HAS NEEDLES when some triangle's
  * longest edge squared is at least 2 * 32 times its area (aspect >= 32:1). For such scenes the fp32 contract - the device and the
- * oracle's float instantiation alike; in f64 nothing changes - (i) pads every box by S * 2^-14 instead of S * 2^-20 and (ii)
- * counts a triangle hit only if the ray's point o + t*d and the triangle's point v0 + u*e1 + v*e2 agree within half a pad in
+ * oracle's float instantiation alike; in f64 nothing changes - (i) pads every box by 40 * S * 2^-20 instead of S * 2^-20 and (ii)
+ * counts a triangle hit only if the ray's point o + t*d and the triangle's point v0 + u*e1 + v*e2 agree within 0.8 pads in
  * every coordinate: an accepted hit then lies inside every box around its part of the triangle, whatever the tree. Both sides decide
  * with THIS function. */
 #define SOL_NEEDLE_ASPECT 32.0

@@ -230,6 +230,7 @@ template <typename R> struct Scene {
   const float* env = nullptr; uint32_t env_w = 0, env_h = 0; R env_scale = 1;  // EXTENSION (SolSceneDesc, abi_version >= 2)
   V3<R> cam_origin, cam_llc, cam_h, cam_v, cam_u, cam_vv; R lens_radius = 0;
   R box_pad = 0;  // fp32 box pad (0 in f64)
+  R tri_delta = 0; // tolerance of the triangle consistency rule (strict_tri): 0.8 box pads
   bool strict_tri = false;  // fp32 only: the scene has needle triangles - fatter pad, consistency rule of hit_triangle (solstrale_hip.h, sol_scene_has_needles)
 
   static V3<R> cv(const double* p) { return {(R)p[0], (R)p[1], (R)p[2]}; }
@@ -256,9 +257,10 @@ template <typename R> struct Scene {
       for (int j = 0; j < 3; ++j) take(d.camera.origin[j]);
       pad = (R)(S * (1.0f / 1048576.0f));
       strict_tri = sol_scene_has_needles(&d) != 0;
-      if (strict_tri) pad = (R)(S * (64.0f / 1048576.0f));  // (S * 2^-14: the consistency tolerance of hit_triangle is half of it)
+      if (strict_tri) pad = (R)(S * (40.0f / 1048576.0f));  // (40 thin pads: the consistency tolerance of hit_triangle is 0.8 of it)
     }
     box_pad = pad;
+    tri_delta = pad * (R)0.8f;
     nodes.resize(d.n_nodes);
     for (uint32_t i = 0; i < d.n_nodes; ++i) {
       for (int k = 0; k < 6; k += 2) {
@@ -360,11 +362,11 @@ template <typename R> struct Tracer {
     if (!contains(tmin, tmax, tt)) return false;
     if (sc.strict_tri) {
       // fp32 contract, scenes with needle triangles (solstrale_hip.h): the ray's point and the triangle's point of this hit must agree
-      // within half a box pad - or (t, u, v) are rounding noise, and whether the "hit" is seen would depend on the boxes around it.
+      // within 0.8 box pads - or (t, u, v) are rounding noise, and whether the "hit" is seen would depend on the boxes around it.
       // (The device checks the CLOSEST hit of a search and searches again behind a failure: the closest of the valid candidates.)
       const V3<R> q = T.v0 + T.e1 * (R)u + T.e2 * (R)v;
       const V3<R> dl = intersection - q;
-      if (!(std::fabs(dl.x) <= sphere_slack && std::fabs(dl.y) <= sphere_slack && std::fabs(dl.z) <= sphere_slack)) return false;
+      if (!(std::fabs(dl.x) <= sc.tri_delta && std::fabs(dl.y) <= sc.tri_delta && std::fabs(dl.z) <= sc.tri_delta)) return false;
     }
     float uv0 = 1.f - u - v;
     UvF uv = {uv0 * T.uv0.u + u * T.uv1.u + v * T.uv2.u, uv0 * T.uv0.v + u * T.uv1.v + v * T.uv2.v};

@@ -699,7 +699,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   S.rzmin = root_box.v[4]; S.rzmax = root_box.v[5];
   S.width = d->width; S.height = d->height; S.shader = d->shader_kind; S.max_depth = d->max_depth;
   S.sphere_slack = box_pad * 0.5f;
-  S.tri_delta = sol_scene_has_needles(d) ? box_pad * 0.5f : 0.0f;
+  S.tri_delta = sol_scene_has_needles(d) ? box_pad * 0.8f : 0.0f;
   s->strict_triangles = S.tri_delta > 0.0f;
   S.env = nullptr; S.env_w = S.env_h = 0; S.env_scale = 1.0f;
   if (has_env) {

@@ -201,7 +201,7 @@ DEV bool better(float t, uint32_t dfs, const Hit& h) {
   return t < h.t || (t == h.t && (SOL_REF_KIND(h.ref) == SOL_REF_NONE || dfs > h.dfs));
 }
 // fp32 contract, scenes with needle triangles (include/solstrale_hip.h): the ray's point o + t*d and the triangle's point
-// v0 + u*e1 + v*e2 of a hit agree within `delta` (half a box pad) in every coordinate - the operation order of oracle.cpp, hit_triangle.
+// v0 + u*e1 + v*e2 of a hit agree within `delta` (0.8 box pads) in every coordinate - the operation order of oracle.cpp, hit_triangle.
 DEV bool tri_hit_consistent(const DTri& T, f3 o, f3 d, float t, float u, float v, float delta) {
   const f3 p = o + d * t;
   const f3 q = mk3(T.v0x, T.v0y, T.v0z) + mk3(T.e1x, T.e1y, T.e1z) * u + mk3(T.e2x, T.e2y, T.e2z) * v;
@@ -648,7 +648,12 @@ DEV void trav_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng, 
 DEV bool trav_accept_or_restart(const DevScene& S, Trav& t, const Stack& st) {
   if (SOL_REF_KIND(t.h.ref) != SOL_REF_TRIANGLE) return true;
   const DTri T = ldg_rec(st.tris + SOL_REF_INDEX(t.h.ref));
-  if (tri_hit_consistent(T, t.o, t.d, t.h.t, t.h.u, t.h.v, S.tri_delta)) return true;
+  // (the shading record of the same hit is wanted next, behind this check: its line is asked for now, so that the two fetches'
+  // latencies overlap instead of following each other)
+  const uint32_t warm = ldg_u32(reinterpret_cast<const uint32_t*>(S.tri_shade + SOL_REF_INDEX(t.h.ref)));
+  const bool ok = tri_hit_consistent(T, t.o, t.d, t.h.t, t.h.u, t.h.v, S.tri_delta);
+  asm volatile("" ::"v"(warm));
+  if (ok) return true;
   const float bt = t.h.t;
   const uint32_t bdfs = t.h.dfs;
   trav_begin<true>(t, t.o, t.d, RAY_MIN_F, __builtin_huge_valf(), S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);

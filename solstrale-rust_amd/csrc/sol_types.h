@@ -195,8 +195,8 @@ struct DevScene {
   // out in the order of their cost in the creation probe. block_work: where a counted render adds up, per local block, its rays.
   const uint32_t* block_of_local;
   uint32_t* block_work;
-  // Scenes with needle triangles (solstrale_hip.h, sol_scene_has_needles): tolerance of the triangle hit's consistency rule, =
-  // sphere_slack; 0: the scene has none and the rule is off. (Last: the fields above keep the offsets the scalar loads were tuned around.)
+  // Scenes with needle triangles (solstrale_hip.h, sol_scene_has_needles): tolerance of the triangle hit's consistency rule, 0.8
+  // box pads; 0: the scene has none and the rule is off. (Last: the fields above keep the offsets the scalar loads were tuned around.)
   float tri_delta;
 };
 
