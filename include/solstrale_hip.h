@@ -179,15 +179,50 @@ typedef struct SolSceneDesc {
   double env_scale;
 } SolSceneDesc;
 
+/* fp32 arithmetic contract, vertex order of a triangle's fp32 record. Moller-Trumbore works in the frame (v0; e1 = v1 - v0, e2 = v2 - v0);
+ * its rounding error grows with |e1| |e2| / sin(angle between them), i.e. - the area being what it is - with the product of the two
+ * edge lengths at v0. The fp32 records (device, and the oracle's float instantiation) therefore start at the vertex OPPOSITE THE LONGEST
+ * EDGE: a cyclic rotation (v0, v1, v2) -> (v_k, v_k+1, v_k+2) - same winding, same normal, same set of points; the texture
+ * coordinates rotate along, so the interpolated values are the same numbers up to rounding. k = 0 unless another start is strictly
+ * better; a triangle that is a LIGHT keeps the reference's order (Triangle::random_direction samples the parallelogram at v0,
+ * triangle.rs:114-117). For a strip-shaped needle of aspect 300:1 this takes the test's noise down by that factor. f64 is untouched. */
+static inline int sol_triangle_rotation(const SolTriangle* t) {
+  const double a[3] = {t->v0v1[0], t->v0v1[1], t->v0v1[2]}, b[3] = {t->v0v2[0], t->v0v2[1], t->v0v2[2]};
+  const double c[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+  const double l01 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], l02 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+  const double l12 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+  /* start k: the edge opposite v_k is v_k+1 v_k+2: k = 0: v1v2 (l12), k = 1: v2v0 (l02), k = 2: v0v1 (l01) */
+  int k = 0;
+  double best = l12;
+  if (l02 > best) { best = l02; k = 1; }
+  if (l01 > best) { k = 2; }
+  return k;
+}
+/* The rotated record: vertex, two edges and the order of the three texture coordinates (index into {uv0, uv1, uv2}). */
+static inline void sol_triangle_rotated(const SolTriangle* t, int k, double v0[3], double e1[3], double e2[3], int uv_of[3]) {
+  int i;
+  for (i = 0; i < 3; ++i) {
+    const double p0 = t->v0[i], a = t->v0v1[i], b = t->v0v2[i];
+    if (k == 1) { v0[i] = p0 + a; e1[i] = b - a; e2[i] = -a; }
+    else if (k == 2) { v0[i] = p0 + b; e1[i] = -b; e2[i] = a - b; }
+    else { v0[i] = p0; e1[i] = a; e2[i] = b; }
+  }
+  uv_of[0] = k % 3; uv_of[1] = (k + 1) % 3; uv_of[2] = (k + 2) % 3;
+}
+
 /* fp32 arithmetic contract, needle triangles. fp32 Moller-Trumbore (src/hittable/triangle.rs:119-140 in single
- * precision) is ill-conditioned for triangles of extreme aspect: it accepts rays that pass hundreds of box pads beside the triangle,
+ * precision) is ill-conditioned for triangles of extreme aspect: it accepts rays that pass many box pads beside the triangle (hundreds, in the
+ * reference's vertex order; the rotation above leaves about one candidate in 10^5 beyond ONE thin pad on a mesh with 300:1 rods),
  * and whether such a phantom is seen would depend on which boxes a traversal tested. A scene HAS NEEDLES when some triangle's
  * longest edge squared is at least 2 * 32 times its area (aspect >= 32:1). For such scenes the fp32 contract - the device and the
- * oracle's float instantiation alike; in f64 nothing changes - (i) pads every box by 40 * S * 2^-20 instead of S * 2^-20 and (ii)
+ * oracle's float instantiation alike; in f64 nothing changes - (i) pads every box by SOL_NEEDLE_PAD * S * 2^-20 instead of S * 2^-20 and (ii)
  * counts a triangle hit only if the ray's point o + t*d and the triangle's point v0 + u*e1 + v*e2 agree within 0.8 pads in
  * every coordinate: an accepted hit then lies inside every box around its part of the triangle, whatever the tree. Both sides decide
  * with THIS function. */
 #define SOL_NEEDLE_ASPECT 32.0
+#ifndef SOL_NEEDLE_PAD
+#define SOL_NEEDLE_PAD 4.0f /* such scenes' box pad, in thin pads (S * 2^-20); the rule's tolerance is 0.8 of it */
+#endif
 static inline int sol_scene_has_needles(const SolSceneDesc* d) {
   uint32_t i;
   for (i = 0; i < d->n_triangles; ++i) {

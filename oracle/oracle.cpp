@@ -257,7 +257,7 @@ template <typename R> struct Scene {
       for (int j = 0; j < 3; ++j) take(d.camera.origin[j]);
       pad = (R)(S * (1.0f / 1048576.0f));
       strict_tri = sol_scene_has_needles(&d) != 0;
-      if (strict_tri) pad = (R)(S * (40.0f / 1048576.0f));  // (40 thin pads: the consistency tolerance of hit_triangle is 0.8 of it)
+      if (strict_tri) pad = (R)(S * (SOL_NEEDLE_PAD / 1048576.0f));  // (the consistency tolerance of hit_triangle is 0.8 of it)
     }
     box_pad = pad;
     tri_delta = pad * (R)0.8f;
@@ -280,10 +280,20 @@ template <typename R> struct Scene {
       quads[i] = {cv(s.q), cv(s.u), cv(s.v), cv(s.normal), cv(s.w), (R)s.d, (R)s.area, s.material, s.dfs_index};
     }
     tris.resize(d.n_triangles);
+    std::vector<uint8_t> is_light(d.n_triangles, 0);
+    for (uint32_t i = 0; i < d.n_lights; ++i)
+      if (SOL_REF_KIND(d.lights[i]) == SOL_REF_TRIANGLE && SOL_REF_INDEX(d.lights[i]) < d.n_triangles) is_light[SOL_REF_INDEX(d.lights[i])] = 1;
     for (uint32_t i = 0; i < d.n_triangles; ++i) {
       const SolTriangle& s = d.triangles[i];
-      tris[i] = {cv(s.v0), cv(s.v0v1), cv(s.v0v2), cv(s.normal), cv(s.tangent), cv(s.bi_tangent), (R)s.area,
-                 {s.uv0[0], s.uv0[1]}, {s.uv1[0], s.uv1[1]}, {s.uv2[0], s.uv2[1]}, s.material, s.dfs_index};
+      // fp32 contract (solstrale_hip.h, sol_triangle_rotation): the float record starts at the vertex opposite the longest edge; f64 and
+      // light triangles keep the reference's order
+      const int k = (sizeof(R) == 4 && !is_light[i]) ? sol_triangle_rotation(&s) : 0;
+      double v0[3], e1[3], e2[3];
+      int uo[3];
+      sol_triangle_rotated(&s, k, v0, e1, e2, uo);
+      const float* uvs[3] = {s.uv0, s.uv1, s.uv2};
+      tris[i] = {cv(v0), cv(e1), cv(e2), cv(s.normal), cv(s.tangent), cv(s.bi_tangent), (R)s.area,
+                 {uvs[uo[0]][0], uvs[uo[0]][1]}, {uvs[uo[1]][0], uvs[uo[1]][1]}, {uvs[uo[2]][0], uvs[uo[2]][1]}, s.material, s.dfs_index};
     }
     meds.resize(d.n_mediums);
     for (uint32_t i = 0; i < d.n_mediums; ++i) meds[i] = {d.mediums[i].boundary, d.mediums[i].material, (R)d.mediums[i].negative_inverse_density, d.mediums[i].dfs_index};

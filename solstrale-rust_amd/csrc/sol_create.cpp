@@ -90,17 +90,29 @@ static int device_world_tree(const std::vector<DNode>& bin, uint32_t root_ref, c
   return SOL_OK;
 }
 
+// A triangle's fp32 intersect record: starts at the vertex opposite the longest edge (fp32 arithmetic contract, solstrale_hip.h
+// sol_triangle_rotation; the oracle's float instantiation makes the same choice), except for lights, which keep the reference's order.
+// uv_of = which of {uv0, uv1, uv2} belongs to the record's three vertices.
+static void cast_triangle(const SolTriangle& t, bool is_light, DTri& o, int uv_of[3]) {
+  double v0[3], e1[3], e2[3];
+  sol_triangle_rotated(&t, is_light ? 0 : sol_triangle_rotation(&t), v0, e1, e2, uv_of);
+  o.v0x = (float)v0[0]; o.v0y = (float)v0[1]; o.v0z = (float)v0[2];
+  o.e1x = (float)e1[0]; o.e1y = (float)e1[1]; o.e1z = (float)e1[2];
+  o.e2x = (float)e2[0]; o.e2y = (float)e2[1]; o.e2z = (float)e2[2];
+  o.dfs = t.dfs_index; o.mat = t.material; o.area = (float)t.area;
+}
+static std::vector<uint8_t> light_triangles(const SolSceneDesc& d) {
+  std::vector<uint8_t> is_light(d.n_triangles, 0);
+  for (uint32_t i = 0; i < d.n_lights; ++i)
+    if (SOL_REF_KIND(d.lights[i]) == SOL_REF_TRIANGLE && SOL_REF_INDEX(d.lights[i]) < d.n_triangles) is_light[SOL_REF_INDEX(d.lights[i])] = 1;
+  return is_light;
+}
 // the triangles' vertices as the device will hold them (what pre-splitting clips)
 static std::vector<DTri> cast_triangles(const SolSceneDesc& d) {
   std::vector<DTri> tris(d.n_triangles);
-  for (uint32_t i = 0; i < d.n_triangles; ++i) {
-    const SolTriangle& t = d.triangles[i];
-    DTri& o = tris[i];
-    o.v0x = (float)t.v0[0]; o.v0y = (float)t.v0[1]; o.v0z = (float)t.v0[2];
-    o.e1x = (float)t.v0v1[0]; o.e1y = (float)t.v0v1[1]; o.e1z = (float)t.v0v1[2];
-    o.e2x = (float)t.v0v2[0]; o.e2y = (float)t.v0v2[1]; o.e2z = (float)t.v0v2[2];
-    o.dfs = t.dfs_index; o.mat = t.material; o.area = (float)t.area;
-  }
+  const std::vector<uint8_t> is_light = light_triangles(d);
+  int uv_of[3];
+  for (uint32_t i = 0; i < d.n_triangles; ++i) cast_triangle(d.triangles[i], is_light[i] != 0, tris[i], uv_of);
   return tris;
 }
 static SolSplitOptions split_options(const SolDevOverrides& ovr, const SolCreateOptions* opt) {
@@ -378,19 +390,18 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   // ---- primitives (plain casts) ----
   std::vector<DTri> tris(d->n_triangles);
   std::vector<DTriShade> tshade(d->n_triangles);
+  const std::vector<uint8_t> tri_is_light = light_triangles(*d);
   for (uint32_t i = 0; i < d->n_triangles; ++i) {
     const SolTriangle& t = d->triangles[i];
     if (!mat_ok(t.material)) return sol_fail(SOL_EINVAL, "triangle %u: bad material", i);
-    DTri& o = tris[i];
-    o.v0x = (float)t.v0[0]; o.v0y = (float)t.v0[1]; o.v0z = (float)t.v0[2];
-    o.e1x = (float)t.v0v1[0]; o.e1y = (float)t.v0v1[1]; o.e1z = (float)t.v0v1[2];
-    o.e2x = (float)t.v0v2[0]; o.e2y = (float)t.v0v2[1]; o.e2z = (float)t.v0v2[2];
-    o.dfs = t.dfs_index; o.mat = t.material; o.area = (float)t.area;
+    int uo[3];
+    cast_triangle(t, tri_is_light[i] != 0, tris[i], uo);
+    const float* uvs[3] = {t.uv0, t.uv1, t.uv2};
     DTriShade& s = tshade[i];
     s.nx = (float)t.normal[0]; s.ny = (float)t.normal[1]; s.nz = (float)t.normal[2]; s.mat = t.material;
     s.tx = (float)t.tangent[0]; s.ty = (float)t.tangent[1]; s.tz = (float)t.tangent[2];
     s.bx = (float)t.bi_tangent[0]; s.by = (float)t.bi_tangent[1]; s.bz = (float)t.bi_tangent[2];
-    s.u0 = t.uv0[0]; s.v0 = t.uv0[1]; s.u1 = t.uv1[0]; s.v1 = t.uv1[1]; s.u2 = t.uv2[0]; s.v2 = t.uv2[1];
+    s.u0 = uvs[uo[0]][0]; s.v0 = uvs[uo[0]][1]; s.u1 = uvs[uo[1]][0]; s.v1 = uvs[uo[1]][1]; s.u2 = uvs[uo[2]][0]; s.v2 = uvs[uo[2]][1];
   }
   std::vector<DQuad> quads(d->n_quads);
   for (uint32_t i = 0; i < d->n_quads; ++i) {

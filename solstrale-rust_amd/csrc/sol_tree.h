@@ -54,9 +54,9 @@ float box_pad_for(const SolSceneDesc& d) {
   else if (k == SOL_REF_MEDIUM && i < d.n_mediums) b = &d.mediums[i].bbox;
   if (b) for (int j = 0; j < 6; ++j) take(b->v[j]);
   for (int j = 0; j < 3; ++j) take(d.camera.origin[j]);
-  // (scenes with needle triangles: 40 times the thin pad, so that a triangle hit the consistency rule accepts - within 0.8 pads of the
+  // (scenes with needle triangles: SOL_NEEDLE_PAD (4) times the thin pad, so that a triangle hit the consistency rule accepts - within 0.8 pads of the
   // triangle - lies inside every box around its part of the triangle with a fifth of a pad to spare: include/solstrale_hip.h)
-  return S * ((sol_scene_has_needles(&d) ? 40.0f : 1.0f) / 1048576.0f);
+  return S * ((sol_scene_has_needles(&d) ? SOL_NEEDLE_PAD : 1.0f) / 1048576.0f);
 }
 
 // Converts the reference-shaped tree (own box per node) into device nodes (child boxes in the parent).

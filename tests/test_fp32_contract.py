@@ -1,0 +1,48 @@
+"""The fp32 arithmetic contract's rules that exist on the CPU side too (include/solstrale_hip.h): checked here on the oracle's two
+instantiations - f64 is the reference's arithmetic and knows none of them."""
+import numpy as np
+
+import orc
+import parity_util as pu
+from solstrale_amd import AlbedoShader, CameraConfig, PathTracingShader, RenderConfig, SceneBuilder, scenes
+
+
+def rotated_record_scene(render_config, needle=60.0):
+    """Three textured triangles whose LONGEST edge is v1v2, v2v0 and v0v1 in turn - the fp32 record starts at v0, v1 and v2
+    (sol_triangle_rotation) - each with distinct texture coordinates per vertex, and a needle-shaped triangle LIGHT, which keeps
+    the reference's vertex order (its random_direction samples the parallelogram at v0, triangle.rs:114-117)."""
+    b = SceneBuilder()
+    cam = CameraConfig(30., 0., (0., 1.2, 11.), (0., 1.2, 0.), (0., 1., 0.))
+    checker = b.Lambertian(b.ImageMap(scenes.load_image("textures/checker.jpg")))
+    light = b.DiffuseLight(12., 11., 10.)
+    uv = ((0.1, 0.1), (1.9, 0.2), (0.3, 1.7))
+    world = [
+        b.Triangle((-3.6, 0., 0.), (-2.2, 0., 0.), (-3.6, 2.5, 0.), checker, None, uv=uv),      # longest edge v1v2: the record starts at v0
+        b.Triangle((-1.6, 0., 0.), (-0.2, 0.05, 0.), (-0.2, 2.6, 0.3), checker, None, uv=uv),   # longest edge v2v0: starts at v1
+        b.Triangle((0.6, 0., -0.2), (3.4, 0.4, 0.2), (1.2, 1.8, 0.), checker, None, uv=uv),     # longest edge v0v1: starts at v2
+        b.Quad((-6., -0.01, -4.), (12., 0., 0.), (0., 0., 8.), b.Lambertian(b.SolidColor(.7, .7, .7))),
+        # the light: a needle whose longest edge is NOT opposite v0
+        b.Triangle((-3., 3.2, 1.), (3., 3.2, 1.0), (-3., 3.2, 1.0 + 6.0 / needle), light),
+    ]
+    return b.finish(b.Bvh(world), cam, (.05, .06, .09), render_config)
+
+
+def test_rotated_records_describe_the_same_surface_and_texture():
+    # albedo at the first hit: the texture through the rotated texture coordinates, f32 (rotated) against f64 (reference order)
+    sc = rotated_record_scene(RenderConfig(160, 120, 4, AlbedoShader()))
+    a, _ = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F32)
+    b, _ = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F64)
+    differing = (np.abs(a - b).max(axis=-1) > 1e-3).mean()
+    assert differing < 0.004, differing  # (a handful of samples on checker and silhouette edges fall the other way)
+    assert abs(a.mean() - b.mean()) < 2e-3 * b.mean()
+
+
+def test_a_triangle_light_keeps_the_reference_order():
+    # path tracing with the needle light sampled: the estimator (the parallelogram at v0) is the same in both instantiations, so the
+    # frames agree up to the few paths that round apart
+    sc = rotated_record_scene(RenderConfig(96, 72, 32, PathTracingShader(8)))
+    a, _ = orc.render(sc, 0, 32, pu.SEED, real=orc.ORC_F32)
+    b, _ = orc.render(sc, 0, 32, pu.SEED, real=orc.ORC_F64)
+    assert b.mean() > 0.05 * 32
+    assert abs(a.mean() - b.mean()) < 3e-3 * b.mean(), (a.mean(), b.mean())
+    assert (np.abs(a - b).max(axis=-1) > 1e-3 * 32).mean() < 0.02

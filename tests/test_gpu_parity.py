@@ -86,7 +86,9 @@ def test_needle_triangles_do_not_make_the_tree_matter(monkeypatch):
         for (x, y, s_) in ((1350, 137, 8), (1895, 966, 26), (578, 56, 468), (1350, 137, 504)):
             rows, colour = ds.debug_path(x, y, s_, pu.SEED)
             orows, ocolour = orc.debug_path(sc, x, y, s_, pu.SEED, real=orc.ORC_F32)
-            assert len(rows) == len(orows) and np.abs(colour - ocolour).max() <= 1e-6 * max(1e-3, float(np.abs(ocolour).max())), (x, y, s_, colour, ocolour)
+            assert np.abs(colour - ocolour).max() <= 1e-6 * max(1e-3, float(np.abs(ocolour).max())), (x, y, s_, colour, ocolour)
+            # (the oracle, like the reference, also follows a scattered ray whose scattering pdf is 0 - weight 0, the device ends the path there)
+            assert 0 < len(rows) <= len(orows), (x, y, s_, len(rows), len(orows))
             for r, o in zip(rows, orows):
                 assert r[6] == o[6] or abs(r[6] - o[6]) <= 1e-6 * abs(o[6]), (x, y, s_, r[:8], o[:8])  # the same hit parameter, ray by ray
         ds.render(0, 64, pu.SEED)
@@ -331,6 +333,19 @@ def test_normal_mapping_quad_and_sphere():
 @pytest.mark.parametrize("half", [0.1, 0.8, None])
 def test_light_attenuation(half):
     assert_parity(scenes.create_light_attenuation_scene(RenderConfig(128, 128, 16), half), 16)
+
+
+def test_fp32_records_start_opposite_the_longest_edge():
+    """fp32 contract (include/solstrale_hip.h, sol_triangle_rotation): the device's triangle records, like the oracle's float ones,
+    start at the vertex opposite the longest edge - all three rotations, texture coordinates rotated along, and a triangle light
+    that keeps the reference's order (tests/test_fp32_contract.py has the scene and checks the float oracle against f64)."""
+    from test_fp32_contract import rotated_record_scene
+    assert_parity(rotated_record_scene(RenderConfig(160, 120, 8, AlbedoShader())), 8)
+    assert_parity(rotated_record_scene(RenderConfig(160, 120, 32, PathTracingShader(8))), 32)
+    sc = rotated_record_scene(RenderConfig(96, 72, 64, PathTracingShader(8)))
+    f64, _ = orc.render(sc, 0, 64, pu.SEED, real=orc.ORC_F64)
+    img = gpu_render(sc, 64)
+    assert abs(img.mean() - f64.mean()) < 3e-3 * f64.mean(), (img.mean(), f64.mean())
 
 
 def test_uv_wrapping():

@@ -22,7 +22,7 @@ if __name__ == "__main__":
         ra, ca = d_split.debug_path(x, y, s, pu.SEED)
         rb, cb = d_plain.debug_path(x, y, s, pu.SEED)
         ro, co = orc.debug_path(sc, x, y, s, pu.SEED, real=orc.ORC_F32)
-        if (ca != cb).any() or np.abs(ca - co).max() > 1e-6 * max(1e-3, np.abs(co).max()):
+        if (ca != cb).any() or np.abs(ca - co).max() > 1e-6 * max(1e-3, np.abs(co).max()) or not (len(ra) == len(rb) == len(ro)):
             print(f"sample {s}: split {ca} plain {cb} oracle {co}; rays {len(ra)} / {len(rb)} / {len(ro)}")
             for k in range(max(len(ra), len(rb), len(ro))):
-                print(f"  ray {k}:\n    split  {fmt(ra[k]) if k < len(ra) else '-'}\n    plain  {fmt(rb[k]) if k < len(rb) else '-'}\n    oracle {fmt(ro[k]) if k < len(ro) else '-'}")
+                print(f"  ray {k}:\n    split  {fmt(ra[k]) if k < len(ra) else '-'}  raw {ra[k][6:] if k < len(ra) else ''}\n    plain  {fmt(rb[k]) if k < len(rb) else '-'}\n    oracle {fmt(ro[k]) if k < len(ro) else '-'}  raw {ro[k][6:] if k < len(ro) else ''}")
