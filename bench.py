@@ -400,7 +400,7 @@ def worker(args):
     # every other rank only LOADS what rank 0 built (or what --no-build promises is there): no second writer in the build directory
     if args.rehearse:
         local_rank = 0
-    from solstrale_amd import DeviceScene, RenderConfig, comm_unique_id, device_count, record_sizes
+    from solstrale_amd import DeviceScene, RenderConfig, _abi, comm_unique_id, device_count, record_sizes
     if device_count() < 1:
         raise SystemExit("bench.py: no HIP device; the hot path has no CPU fallback")
     dev = None
@@ -424,7 +424,6 @@ def worker(args):
         # the ONE communicator of the run lives behind the C ABI (sol_comm_init: ncclCommInitRank); the store only ships the id
         uid = coord.bcast(bytes(comm_unique_id()) if rank == 0 else None)
         if args.partition == "balanced":  # blocks dealt out by their cost in the creation probe (every rank derives the same table)
-            from solstrale_amd import _abi
             ds.set_option(_abi.OPT_BALANCED_PARTITION, 1)
         ds.comm_init(rank, world, uid)
         rccl_ranks = world
@@ -494,10 +493,22 @@ def worker(args):
     ds.render(0, c_spp, SEED, counted=True)
     st = ds.stats()
     sizes = record_sizes()
-    bytes_per_sample = algorithmic_bytes(st, sizes) / st["samples"]
-    rays_per_sample = st["rays"] / st["samples"]
+    rays_per_sample = st["rays"] / st["samples"]  # of the whole algorithm: a counted render traces every sample
     launch_samples = st["samples"] // c_spp * last_call_spp  # samples of the launch k_ms belongs to (this rank)
     pst = ds.path_stats()
+    # Background blocks (SolSceneInfo::background_blocks: blocks proved at scene creation to see only the constant background are summed,
+    # not traced). What the timed launches touched is counted by a second counted render that skips them as a plain render does: the
+    # roofline's algorithmic bytes and the Mrays/s below are those of the rays actually traced, never of rays that were not.
+    st_traced = st
+    if tree_info["background_blocks"] > 0 and not os.environ.get("SOL_BACKGROUND_BLOCKS") == "0":
+        ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, 2)
+        ds.clear()
+        ds.render(0, c_spp, SEED, counted=True)
+        st_traced = ds.stats()
+        ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, 1)
+    background_samples = st["samples"] - st_traced["samples"]
+    bytes_per_sample = (algorithmic_bytes(st_traced, sizes) + background_samples * 12.0 / 16.0 * 3.0) / st["samples"]
+    traced_rays_per_sample = st_traced["rays"] / st["samples"]
 
     out = None
     if rank == 0:
@@ -515,10 +526,17 @@ def worker(args):
                        "sharding": f"8x8 tiles " + ("dealt out by probe cost" if (world > 1 and args.partition == "balanced") else "round-robin") + f" over {world} rank(s); every rank renders its tiles with all {spp} spp; "
                                    f"gather to rank 0 " + ("inside the C ABI (sol_gather: grouped ncclSend/ncclRecv)" + (" over the one-GPU test transport stub" if args.rehearse else "")
                                                            if world > 1 else "(single rank: un-permute only)")},
-            "mrays_per_s": round(value * rays_per_sample, 2),
+            "mrays_per_s": round(value * traced_rays_per_sample, 2),
             "rays_per_sample": round(rays_per_sample, 4),
-            "node_visits_per_ray": round(st["node_visits"] / max(1, st["rays"]), 3),
-            "primitive_tests_per_ray": round((st["triangle_tests"] + st["quad_tests"] + st["sphere_tests"]) / max(1, st["rays"]), 3),
+            "traced_rays_per_sample": round(traced_rays_per_sample, 4),
+            "background_blocks": {"blocks": tree_info["background_blocks"], "sample_fraction": round(background_samples / st["samples"], 4),
+                                  "note": "8x8 pixel blocks of which sol_scene_create proved that no camera ray of theirs, whatever the jitter, comes near a "
+                                          "primitive's box: every sample is the background colour, summed in the reference's order without being traced "
+                                          "(frames bit-identical with SOL_OPT_BACKGROUND_BLOCKS 0; SOL_BACKGROUND_BLOCKS=0 in the environment switches the proof off). "
+                                          "mrays_per_s, traced_rays_per_sample and the roofline's algorithmic bytes count only what was traced; rays_per_sample, the "
+                                          "histogram and primary_hit_fraction describe the whole algorithm (one camera ray per background sample)"},
+            "node_visits_per_ray": round(st_traced["node_visits"] / max(1, st_traced["rays"]), 3),
+            "primitive_tests_per_ray": round((st_traced["triangle_tests"] + st_traced["quad_tests"] + st_traced["sphere_tests"]) / max(1, st_traced["rays"]), 3),
             "primary_hit_fraction": round(pst["primary_hit_fraction"], 4),
             "rays_per_path_histogram": {k: round(v, 4) for k, v in pst["rays_per_path_histogram"].items()},
             "rays_per_sample_note": "the open-roofed atrium ends most paths on the sky after ~3 rays; a closed interior costs several "
@@ -534,7 +552,7 @@ def worker(args):
                          "kernel": "sol_render_kernel", "kernel_ms": round(k_ms, 3), "grid_blocks": grid,
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
                          "samples_per_launch": int(launch_samples),
-                         "counters_per_sample": {k: round(v / st["samples"], 4) for k, v in st.items() if k not in ("samples", "max_stack")}},
+                         "counters_per_sample": {k: round(v / st["samples"], 4) for k, v in st_traced.items() if k not in ("samples", "max_stack")}},
             "setup_s": {"scene_and_bvh_build_host": round(t_build, 2), "sol_scene_create": round(t_upload, 2),
                         **{"create_" + k: round(v, 3) for k, v in bt.items()}},
             "world_tree": {"builder": tree_info["tree_name"], "presplit_extra_references": tree_info["split_references"],

@@ -284,7 +284,8 @@ typedef struct SolCreateOptions {
                                triangles stay unsplit); > 0: that budget, always used; < 0: no pre-splitting                   */
   int32_t reinsertion_rounds; /* device build: rounds of parallel reinsertion after the clustering (every node looks for the place
                                where its sub-tree adds the least surface area; results do not change). 0: the default, < 0: none  */
-  int32_t reserved[3];
+  int32_t no_background_blocks; /* 1: do not look for background blocks (below, SolSceneInfo::background_blocks)            */
+  int32_t reserved[2];
 } SolCreateOptions;
 int sol_scene_create_ex(const SolSceneDesc* desc, int device, const SolCreateOptions* options, SolScene** out);
 /* Seconds sol_scene_create spent in: [0] host tree candidates, [1] uploads, [2] device tree build, [3] probe renders. */
@@ -310,6 +311,12 @@ typedef struct SolSceneInfo {
   uint32_t partition_crc;    /* checksum of the block -> (rank, local block) mapping in force: equal on every rank of a job, or the
                                 ranks render different partitions (each derives the table from its own probe)                     */
   uint32_t strict_triangles; /* 1: the scene has needle triangles (sol_scene_has_needles): fatter box pad, triangle consistency rule  */
+  uint32_t background_blocks; /* 8x8 pixel blocks of which sol_scene_create PROVED that no camera ray of any of their pixels, whatever the
+                                jitter, comes near a primitive's box (pinhole camera, constant background, the world a tree: the pyramid of
+                                the block's rays against the world tree's boxes, conservatively). Every sample of such a pixel is the
+                                background colour; sol_render adds those sums up in the reference's order without generating the
+                                samples (SOL_OPT_BACKGROUND_BLOCKS). Images never depend on it. 0: none found, or not looked for     */
+  uint32_t background_pixels; /* pixels of the image inside those blocks                                                        */
 } SolSceneInfo;
 int sol_scene_info(const SolScene* scene, SolSceneInfo* out);
 
@@ -326,6 +333,10 @@ int sol_scene_info(const SolScene* scene, SolSceneInfo* out);
                                          sol_gather / sol_read / sol_unpermute of THIS library - a caller with its own collective and
                                          un-permute keeps the default 0, whose layout it can compute. Set it on every rank, before
                                          sol_comm_init. Images never depend on it.                                              */
+#define SOL_OPT_BACKGROUND_BLOCKS 7   /* 1 (default): the samples of background blocks (SolSceneInfo::background_blocks) are summed without
+                                         being traced; 0: every sample of every pixel is generated and traced. Images never depend on it;
+                                         counted renders (sol_render_counted) trace everything - their counters describe the whole
+                                         algorithm - unless the value is 2: then they count exactly what a plain render does.      */
 int sol_scene_set_option(SolScene* scene, int option, int64_t value);
 
 /* Image-tile sharding for one-process-per-GPU runs (no reference analogue). The image is cut
@@ -456,6 +467,9 @@ typedef struct SolTreeCheck {
   uint32_t reserved;
 } SolTreeCheck;
 int sol_world_tree_check(const SolSceneDesc* desc, int use_sah, SolTreeCheck* out);
+/* Diagnostic, host only: the background blocks (SolSceneInfo::background_blocks) found with the host-built tree `use_sah` (>= 0) names:
+ * flags[b] = 1 for block b (row-major, (width + 7) / 8 blocks per row), *n_found their number. flags may be NULL. */
+int sol_background_blocks(const SolSceneDesc* desc, int use_sah, uint8_t* flags, size_t n_flags, uint32_t* n_found);
 
 /* Diagnostic: traces the single path (pixel x, y counted from the image top; sample index) and writes 12 floats per ray
  * (origin xyz, direction xyz, hit t, hit reference bits, dfs index bits, depth, 0, 0), closed by a row holding the sample's

@@ -48,6 +48,7 @@ SolDevOverrides sol_dev_overrides() {
   o.split_percent = num("SOL_SPLIT", -1);
   o.split_slack = num("SOL_SPLIT_SLACK", -1);
   o.split_keep = num("SOL_SPLIT_KEEP", -1);
+  o.background_blocks = num("SOL_BACKGROUND_BLOCKS", -1);
   o.reinsert_rounds = num("SOL_REINSERT", -1);
   o.reinsert_stride = std::max(0, num("SOL_REINSERT_STRIDE", 0));
   o.order_mode = num("SOL_ORDER", 2);
@@ -67,25 +68,37 @@ SolDevOverrides sol_dev_overrides() {
 int sol_rebuild_order(SolScene* s) {
   s->S.block_order = nullptr;
   s->S.n_first = 0;
+  s->n_background_local = 0;
   const uint32_t n = s->n_local_blocks;
-  if (!s->order_enabled || s->block_cost.empty() || n < 2) return SOL_OK;
-  std::vector<uint32_t> cost(n);
+  auto global_of = [&](uint32_t lb) -> size_t { return s->local_blocks.empty() ? (size_t)lb * s->world + s->rank : s->local_blocks[lb]; };
+  // background blocks (SolSceneInfo::background_blocks) go LAST, whatever else the order does: a launch that does not trace them
+  // stops in front of them (RenderParams::n_traced_blocks)
+  std::vector<uint32_t> background;
+  std::vector<uint8_t> is_background(n, 0);
+  for (uint32_t lb = 0; lb < n && !s->background_block.empty(); ++lb) {
+    const size_t b = global_of(lb);
+    if (b < s->background_block.size() && s->background_block[b]) { is_background[lb] = 1; background.push_back(lb); }
+  }
+  const bool by_cost = s->order_enabled && !s->block_cost.empty() && n >= 2;
+  if (!by_cost && background.empty()) return SOL_OK;
+  std::vector<uint32_t> cost(n, 0u);
   double sum = 0.;
-  for (uint32_t lb = 0; lb < n; ++lb) {
-    const size_t b = s->local_blocks.empty() ? (size_t)lb * s->world + s->rank : s->local_blocks[lb];
+  for (uint32_t lb = 0; lb < n && by_cost; ++lb) {
+    const size_t b = global_of(lb);
     cost[lb] = b < s->block_cost.size() ? s->block_cost[b] : 0u;
     sum += cost[lb];
   }
   const double limit = 3.0 * sum / n;
   std::vector<uint32_t> heavy, rest;
-  for (uint32_t lb = 0; lb < n; ++lb) (cost[lb] > limit ? heavy : rest).push_back(lb);
+  for (uint32_t lb = 0; lb < n; ++lb)
+    if (!is_background[lb]) (by_cost && cost[lb] > limit ? heavy : rest).push_back(lb);
   // The rest keeps the chunk-major order, but within a chunk the blocks go from costly to cheap in eight cost classes (octiles of
   // the probe's ray counts; raster order inside a class, so neighbours stay together): the launch then ENDS on the cheapest blocks
   // (sky) of the last chunk instead of on whatever the raster order ends on (floor and walls: one 16-sample item of a long path
   // is milliseconds of one lane). A fixed ~6 ms of tail per launch otherwise - 1 % of a 1080p x 512 spp frame on one GPU, 7 % of
   // its eighth on eight.
   const int order_mode = s->order_mode;  // (SOL_ORDER) 1: heavy-first only (round 1)
-  if (order_mode >= 2 && rest.size() >= 64) {
+  if (by_cost && order_mode >= 2 && rest.size() >= 64) {
     std::vector<uint32_t> sorted_cost;
     sorted_cost.reserve(rest.size());
     for (uint32_t lb : rest) sorted_cost.push_back(cost[lb]);
@@ -94,11 +107,13 @@ int sol_rebuild_order(SolScene* s) {
     for (int k = 0; k < 7; ++k) edge[k] = sorted_cost[(size_t)(k + 1) * sorted_cost.size() / 8];
     auto cls = [&](uint32_t lb) { int c = 0; while (c < 7 && cost[lb] >= edge[c]) ++c; return c; };
     std::stable_sort(rest.begin(), rest.end(), [&](uint32_t a, uint32_t b) { return cls(a) > cls(b); });
-  } else if (heavy.empty() || rest.empty()) {
+  } else if ((heavy.empty() || rest.empty()) && background.empty()) {
     return SOL_OK;
   }
   std::stable_sort(heavy.begin(), heavy.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+  const uint32_t n_first = rest.empty() ? 0u : (uint32_t)heavy.size();  // (nothing but heavy blocks: they are the chunk-major "rest")
   heavy.insert(heavy.end(), rest.begin(), rest.end());
+  heavy.insert(heavy.end(), background.begin(), background.end());
   if (n > s->order_cap) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->order_dev) hipFree(s->order_dev);
@@ -109,7 +124,8 @@ int sol_rebuild_order(SolScene* s) {
   HIP_TRY(hipStreamSynchronize(s->stream));  // a launch in flight may still read the old table
   HIP_TRY(hipMemcpy(s->order_dev, heavy.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
   s->S.block_order = s->order_dev;
-  s->S.n_first = (uint32_t)(heavy.size() - rest.size());
+  s->S.n_first = n_first;
+  s->n_background_local = (uint32_t)background.size();
   return SOL_OK;
 }
 
@@ -232,6 +248,8 @@ int sol_scene_info(const SolScene* s, SolSceneInfo* out) {
   r.partition_table = s->partition_table;
   r.partition_crc = s->partition_crc;
   r.strict_triangles = s->strict_triangles ? 1u : 0u;
+  r.background_blocks = s->n_background;
+  r.background_pixels = s->background_pixels;
   std::memcpy(out, &r, r.size);
   return SOL_OK;
 }
@@ -277,6 +295,10 @@ int sol_scene_set_option(SolScene* s, int option, int64_t value) {
         const int rc = sol_set_partition(s, s->rank, s->world);
         if (rc != SOL_OK) { s->balanced = before; return rc; }
       }
+      return SOL_OK;
+    case SOL_OPT_BACKGROUND_BLOCKS:
+      s->background_enabled = value != 0;
+      s->background_in_counted = value == 2;
       return SOL_OK;
     case SOL_OPT_WORK_ORDER:
       s->order_enabled = value != 0;

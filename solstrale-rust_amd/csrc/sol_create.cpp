@@ -115,6 +115,133 @@ static std::vector<DTri> cast_triangles(const SolSceneDesc& d) {
   for (uint32_t i = 0; i < d.n_triangles; ++i) cast_triangle(d.triangles[i], is_light[i] != 0, tris[i], uv_of);
   return tris;
 }
+// Background blocks (include/solstrale_hip.h, SolSceneInfo::background_blocks): the 8x8 pixel blocks of which it can be PROVED that
+// every camera ray of every pixel, whatever the jitter and the lens sample, sees nothing - so that every sample is the background
+// colour and none has to be generated. A ray of the block (generate_path; Camera::get_ray, src/camera.rs:77-89) leaves a point L of
+// the lens - the eye, or eye + lens_radius * (x u + y w) with (x, y) in the unit disc - towards a point T of the focal plane's
+// rectangle of the block's pixels. Both sets are bounded by quadrilaterals (the lens disc's square; the rectangle widened by a whole
+// pixel on every side: the fp32 rounding of generate_path is 10^-7 of that). For a plane normal n all those rays lie in the half
+// space n . x <= a with a = max n . L as soon as b = max n . (T - L) <= 0, both maxima taken over the corners (n . (T - L) is linear in
+// T and in L): candidate normals come from the rectangle's edges and the lens corners (and the viewing direction, for what lies behind
+// the camera), built from slightly LARGER quadrilaterals so that the check b <= 0 on the real ones holds with room to spare, and a
+// candidate that fails the check is simply not used. The ray set so bounded walks the DEVICE tree as the kernel decodes it, every
+// child box inflated by `margin` (64 box pads: the kernel's and the oracle's fp32 slab tests err by about one); a box is passed
+// only when a valid plane has the whole box on its outer side. A block whose rays reach no primitive's (leaf) box is a background
+// block: for each of its rays the kernel would find every leaf box missed - the quantised leaf boxes contain the primitives' own
+// padded boxes, which the reference tree of the oracle tests -, so no primitive test would run on either side.
+// Conservative in every step (a block near a silhouette is traced like any other); images never depend on it.
+static void find_background_blocks(const WideLayout& L, uint32_t emin, const DCamera& cam, uint32_t width, uint32_t height, double margin,
+                                   std::vector<uint8_t>& flags, uint32_t& n_found, uint32_t& n_pixels) {
+  const uint32_t bx_n = (width + SOL_TILE - 1) / SOL_TILE, by_n = (height + SOL_TILE - 1) / SOL_TILE;
+  flags.assign((size_t)bx_n * by_n, 0);
+  n_found = 0; n_pixels = 0;
+  if (L.nodes.empty() || width < 2 || height < 2 || !(cam.lens_radius >= 0.0f) || !std::isfinite(cam.lens_radius)) return;
+  struct V { double x, y, z; };
+  auto dot = [](const V& a, const V& b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+  auto cross = [](const V& a, const V& b) { return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+  auto sub = [](const V& a, const V& b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; };
+  const V org{cam.ox, cam.oy, cam.oz}, ll{cam.llx, cam.lly, cam.llz}, hh{cam.hx, cam.hy, cam.hz}, vv{cam.vx, cam.vy, cam.vz};
+  const V lu{cam.ux, cam.uy, cam.uz}, lw{cam.wx, cam.wy, cam.wz};
+  // the lens: corners of the square around the disc (one point for a pinhole), and of a larger one for the candidate planes
+  const int n_lens = cam.lens_radius > 0.0f ? 4 : 1;
+  V lens[4], lens_wide[4];
+  for (int k = 0; k < 4; ++k) {
+    const double sx = (k == 0 || k == 3) ? -1. : 1., sy = k < 2 ? -1. : 1., r = (double)cam.lens_radius * 1.0001, rw = (double)cam.lens_radius * 1.05;
+    lens[k] = V{org.x + (lu.x * sx + lw.x * sy) * r, org.y + (lu.y * sx + lw.y * sy) * r, org.z + (lu.z * sx + lw.z * sy) * r};
+    lens_wide[k] = V{org.x + (lu.x * sx + lw.x * sy) * rw, org.y + (lu.y * sx + lw.y * sy) * rw, org.z + (lu.z * sx + lw.z * sy) * rw};
+  }
+  struct Plane { V n; double a; };
+  std::vector<uint32_t> stack;
+  for (uint32_t by = 0; by < by_n; ++by)
+    for (uint32_t bx = 0; bx < bx_n; ++bx) {
+      const uint32_t x0 = bx * SOL_TILE, x1 = std::min(x0 + SOL_TILE, width), y0 = by * SOL_TILE, y1 = std::min(y0 + SOL_TILE, height);
+      // generate_path: u = (px + r) / (W - 1), v = ((H - 1 - py) + r) / (H - 1), r in [0, 1); `grow` pixels of margin on every side
+      auto corners = [&](double grow, V t[4]) {
+        const double u0 = ((double)x0 - grow) / (double)(width - 1), u1 = ((double)x1 + grow) / (double)(width - 1);
+        const double v0 = ((double)height - (double)y1 - grow) / (double)(height - 1), v1 = ((double)height - (double)y0 + grow) / (double)(height - 1);
+        const double cu[4] = {u0, u1, u1, u0}, cv[4] = {v0, v0, v1, v1};
+        for (int k = 0; k < 4; ++k) t[k] = V{ll.x + hh.x * cu[k] + vv.x * cv[k], ll.y + hh.y * cu[k] + vv.y * cv[k], ll.z + hh.z * cu[k] + vv.z * cv[k]};
+      };
+      V T[4], Tw[4];
+      corners(1.0, T);
+      corners(2.0, Tw);
+      Plane plane[17];
+      int n_planes = 0;
+      // keeps the candidate n (pointing AWAY from the rays) if every ray of the block provably stays in n . x <= a
+      auto offer = [&](V n) {
+        const double len = std::sqrt(dot(n, n));
+        if (!(len > 0.) || !std::isfinite(len)) return;
+        double a = -1e300, b = -1e300;
+        for (int j = 0; j < n_lens; ++j) {
+          a = std::max(a, dot(n, lens[j]));
+          for (int k = 0; k < 4; ++k) b = std::max(b, dot(n, sub(T[k], lens[j])));
+        }
+        if (b <= 0.) plane[n_planes++] = Plane{n, a};
+      };
+      for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < n_lens; ++j) {
+          const V& Lj = n_lens == 1 ? org : lens_wide[j];
+          V n = cross(sub(Tw[(k + 1) & 3], Tw[k]), sub(Tw[k], Lj));
+          if (dot(n, sub(Tw[(k + 2) & 3], Lj)) > 0.) n = V{-n.x, -n.y, -n.z};  // the rectangle's far side is inside
+          offer(n);
+        }
+      {
+        const V c{T[0].x + T[1].x + T[2].x + T[3].x - 4. * org.x, T[0].y + T[1].y + T[2].y + T[3].y - 4. * org.y, T[0].z + T[1].z + T[2].z + T[3].z - 4. * org.z};
+        offer(V{-c.x, -c.y, -c.z});  // what lies behind the camera
+      }
+      if (n_planes == 0) continue;
+      // the least value of n . p over a box: > a = the whole box on the outer side
+      auto outside = [&](const double lo[3], const double hi[3]) {
+        for (int k = 0; k < n_planes; ++k) {
+          const V& n = plane[k].n;
+          const double m = std::min(n.x * lo[0], n.x * hi[0]) + std::min(n.y * lo[1], n.y * hi[1]) + std::min(n.z * lo[2], n.z * hi[2]);
+          if (m > plane[k].a) return true;
+        }
+        return false;
+      };
+      bool reached = false;
+      uint32_t visits = 0;
+      stack.assign(1, 0u);
+      while (!stack.empty() && !reached) {
+        const uint32_t ni = stack.back();
+        stack.pop_back();
+        if (ni >= L.nodes.size() || ++visits > 4096u) { reached = true; break; }
+        const DWide& w = L.nodes[ni];
+        const float origin[3] = {w.ox, w.oy, w.oz};
+        float scale[3];
+        for (int a = 0; a < 3; ++a) { const uint32_t bits = (((w.meta >> (5 * a)) & 31u) + emin) << 23; std::memcpy(&scale[a], &bits, 4); }
+        const uint32_t imask = (w.meta >> 15) & 0x7Fu, lmask = (w.meta >> 22) & 0x7Fu;
+        for (int sl = 0; sl < SOL_WIDE_CHILDREN; ++sl) {
+          const uint32_t bit = 1u << sl;
+          if (!((imask | lmask) & bit)) continue;
+          double lo[3], hi[3];
+          for (int a = 0; a < 3; ++a) {
+            const uint32_t ql = (w.q[2 * a + (sl >> 2)] >> (8 * (sl & 3))) & 0xFFu, qh = (w.q[6 + 2 * a + (sl >> 2)] >> (8 * (sl & 3))) & 0xFFu;
+            lo[a] = (double)WideBuilder::decode(origin[a], ql, scale[a]) - margin;
+            hi[a] = (double)WideBuilder::decode(origin[a], qh, scale[a]) + margin;
+          }
+          if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) { reached = true; break; }  // (not a box: trace)
+          if (outside(lo, hi)) continue;
+          if (lmask & bit) { reached = true; break; }
+          stack.push_back(WideLayout::base_inner(w) + (uint32_t)__builtin_popcount(imask & (bit - 1u)));
+        }
+      }
+      if (!reached) {
+        flags[(size_t)by * bx_n + bx] = 1;
+        n_found++;
+        n_pixels += (x1 - x0) * (y1 - y0);
+      }
+    }
+}
+
+static DCamera cast_camera(const SolCamera& c) {
+  return DCamera{(float)c.origin[0], (float)c.origin[1], (float)c.origin[2],
+                 (float)c.lower_left_corner[0], (float)c.lower_left_corner[1], (float)c.lower_left_corner[2],
+                 (float)c.horizontal[0], (float)c.horizontal[1], (float)c.horizontal[2],
+                 (float)c.vertical[0], (float)c.vertical[1], (float)c.vertical[2],
+                 (float)c.u[0], (float)c.u[1], (float)c.u[2], (float)c.v[0], (float)c.v[1], (float)c.v[2],
+                 (float)c.lens_radius};
+}
 static SolSplitOptions split_options(const SolDevOverrides& ovr, const SolCreateOptions* opt) {
   SolSplitOptions sp;  // (the default: a budget of 30 %, kept when the splits shrink the primitives' summed box area below 85 %)
   if (opt && opt->split_percent < 0) sp.budget = 0.f;
@@ -301,6 +428,41 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
   }
   for (const auto& f : found)
     if (!expected.count(f.first)) out->leaf_mismatches += (uint32_t)f.second;
+  return SOL_OK;
+}
+
+// Diagnostic, host only: the background blocks sol_scene_create would find with the host-built tree `use_sah` names (as in
+// sol_world_tree_check; the proof does not depend on which tree carries it, the count may).
+int sol_background_blocks(const SolSceneDesc* d, int use_sah, uint8_t* flags, size_t n_flags, uint32_t* n_found) {
+  if (!d || !n_found || use_sah < 0) return sol_fail(SOL_EINVAL, "bad argument");
+  *n_found = 0;
+  const uint32_t nb = ((d->width + SOL_TILE - 1) / SOL_TILE) * ((d->height + SOL_TILE - 1) / SOL_TILE);
+  if (flags && n_flags < nb) return sol_fail(SOL_EINVAL, "%zu flags for %u blocks", n_flags, nb);
+  const SolDevOverrides ovr = sol_dev_overrides();
+  const float box_pad = box_pad_for(*d);
+  TreeBuilder tb(*d, box_pad);
+  uint32_t root_ref;
+  Box root_box;
+  if (!tb.resolve(d->root, 0, root_ref, root_box)) return sol_fail(SOL_EINVAL, "world: %s", tb.error.c_str());
+  if (SOL_REF_KIND(root_ref) != SOL_REF_NODE) return sol_fail(SOL_EINVAL, "the world is a single primitive: no tree");
+  SahBuilder sah;
+  if (!sah.collect(tb.nodes, root_ref)) return sol_fail(SOL_EINVAL, "the world's primitives cannot be collected (non-finite box or fewer than two)");
+  uint32_t bin_root = root_ref;
+  if (use_sah) { Box b; sah.BINS = use_sah > 1 ? std::min((int)SahBuilder::MAX_BINS, use_sah) : 16; bin_root = sah.build(0, sah.prims.size(), 0, b); }
+  WideBuilder wb(use_sah ? sah.nodes : tb.nodes, box_pad);
+  wb.dp_collapse = !ovr.greedy_collapse;
+  wb.slot_by_assignment = !ovr.octant_slots;
+  wb.NODE_COST = ovr.node_cost;
+  wb.set_exponent_range(root_box);
+  const uint32_t xroot = wb.build(SOL_REF_INDEX(bin_root), 0);
+  WideLayout lay;
+  if (wb.range_error || !lay.run(wb.out, SOL_REF_INDEX(xroot), wb.emin, d->n_triangles, d->n_spheres, d->n_quads))
+    return sol_fail(SOL_EINVAL, "wide tree layout: %s", wb.range_error ? "exponent range" : lay.error.c_str());
+  const bool has_env = d->abi_version >= 2u && d->env_texels && d->env_width && d->env_height;
+  std::vector<uint8_t> f(nb, 0);
+  uint32_t pixels = 0;
+  if (!has_env) find_background_blocks(lay, wb.emin, cast_camera(d->camera), d->width, d->height, 64.0 * (double)box_pad, f, *n_found, pixels);
+  if (flags) std::memcpy(flags, f.data(), nb);
   return SOL_OK;
 }
 
@@ -719,13 +881,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     S.env = s->env; S.env_w = d->env_width; S.env_h = d->env_height; S.env_scale = (float)d->env_scale;
   }
   S.bgx = (float)d->background[0]; S.bgy = (float)d->background[1]; S.bgz = (float)d->background[2];
-  const SolCamera& c = d->camera;
-  S.cam = DCamera{(float)c.origin[0], (float)c.origin[1], (float)c.origin[2],
-                  (float)c.lower_left_corner[0], (float)c.lower_left_corner[1], (float)c.lower_left_corner[2],
-                  (float)c.horizontal[0], (float)c.horizontal[1], (float)c.horizontal[2],
-                  (float)c.vertical[0], (float)c.vertical[1], (float)c.vertical[2],
-                  (float)c.u[0], (float)c.u[1], (float)c.u[2], (float)c.v[0], (float)c.v[1], (float)c.v[2],
-                  (float)c.lens_radius};
+  S.cam = cast_camera(d->camera);
   s->kernel_version = ovr.kernel_version;
   s->order_mode = ovr.order_mode;
   // v1's search/shade switch (RenderParams::switch_below), measured on MI355X at 1080p x 128 spp (ms, C1 / C2 / C3 / test scene):
@@ -748,6 +904,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   }
   s->tree_name = cands[0].name;
   s->tree_note = fallback_note;
+  size_t chosen = 0;  // the candidate the scene keeps
   if (calibrate) {
     // Probe every candidate tree with a counted render of 16 samples per pixel over ~256 pixel blocks spread across the image
     // and keep the one with the least search work (a wide-node visit weighs ~2.5 primitive tests, by instruction count).
@@ -781,6 +938,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     }
     if (hipStreamSynchronize(s->stream) != hipSuccess && !rc) rc = SOL_EDEVICE;
     swap_in(pick);
+    chosen = pick;
     s->tree_name = cands[pick].name;
     adopt_info(pick);
     free_cands();
@@ -788,6 +946,14 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     s->stats = SolStats{};
     if ((rc = sol_set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  // Background blocks: constant background only (an environment map is looked up per ray)
+  if (!opt.no_background_blocks && ovr.background_blocks != 0 && !has_env) {
+    find_background_blocks(cands[chosen].lay, cands[chosen].emin, S.cam, d->width, d->height, 64.0 * (double)box_pad, s->background_block,
+                           s->n_background, s->background_pixels);
+    if (ovr.verbose) std::fprintf(stderr, "[solstrale] background blocks: %u of %u (%u pixels)\n", s->n_background, s->blocks_x * s->blocks_y, s->background_pixels);
+    if (s->n_background == 0) s->background_block.clear();
+    else if ((rc = sol_rebuild_order(s))) return rc;  // (also without the cost probe below)
   }
   // Cost probe: per 8x8 block, the ray count of the longest 4-sample item in a counted render of the whole frame, for the
   // heavy-first work order

@@ -28,18 +28,23 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   P.rank = (uint32_t)s->rank; P.world = (uint32_t)s->world;
   P.n_local_blocks = s->n_local_blocks; P.blocks_x = s->blocks_x;
   P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
-  const uint64_t items = (uint64_t)P.n_chunks * P.n_local_blocks * 64u;
+  int version = s->kernel_version ? s->kernel_version : 1;
+  // Background blocks - the tail of the work order - are not traced: their sums are written by sol_fill_background_kernel. Counted
+  // renders trace everything (their counters describe the whole algorithm; the creation probes are counted renders).
+  P.n_traced_blocks = P.n_local_blocks;
+  if (version == 1 && (!count || s->background_in_counted) && s->background_enabled && s->S.block_order && s->n_background_local <= P.n_local_blocks)
+    P.n_traced_blocks = P.n_local_blocks - s->n_background_local;
+  const uint64_t items = (uint64_t)P.n_chunks * P.n_traced_blocks * 64u;
   // the 32-bit work counter keeps counting after the items run out (every wave adds 64 per refused fetch until all its
   // lanes have left): 16 M of headroom is > 100 times what 5120 resident waves can add
-  if (items > SOL_MAX_ITEMS) return sol_fail(SOL_EINVAL, "too many work items in one call (%llu): split the sample range", (unsigned long long)items);
+  if ((uint64_t)P.n_chunks * P.n_local_blocks * 64u > SOL_MAX_ITEMS) return sol_fail(SOL_EINVAL, "too many work items in one call (%llu): split the sample range", (unsigned long long)items);
   P.n_items = (uint32_t)items;
-  if (P.n_items == 0) return SOL_OK;
+  if (P.n_local_blocks == 0) return SOL_OK;
   P.switch_below = s->switch_below;
   // Kernel choice. The product library carries ONE render kernel family, the one-path-per-lane kernel (version 1); the two
   // wavefront variants (2: wave-private pool, 3: two-kernel wavefront; bit-identical images) exist in -DSOL_AB_KERNELS builds for
   // A/B runs: they raise the search's lane occupancy (0.45 -> 0.67-0.73) but pay for it in state traffic, refill stalls and
   // per-round tails (MI355X, C3, 128 spp: v1 997, v2 905, v3 684 Msamples/s when they were last compared).
-  int version = s->kernel_version ? s->kernel_version : 1;
   if (version != 1 && s->strict_triangles) return sol_fail(SOL_EINVAL, "kernel variant %d does not implement the consistency rule of scenes with needle triangles", version);
 #ifndef SOL_AB_KERNELS
   if (version != 1) return sol_fail(SOL_EINVAL, "kernel variant %d exists only in -DSOL_AB_KERNELS builds of the library", version);
@@ -49,7 +54,7 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
 #endif
   if (s->max_bpc > 0) bpc = std::max(1, std::min(bpc, s->max_bpc));  // SOL_OPT_MAX_BLOCKS_PER_CU
   uint32_t grid = (uint32_t)(s->n_cu * bpc);
-  const uint32_t need_blocks = (P.n_items + SOL_WG - 1) / SOL_WG;
+  const uint32_t need_blocks = std::max(1u, (P.n_items + SOL_WG - 1) / SOL_WG);
   if (grid > need_blocks) grid = need_blocks;
   P.total_threads = grid * SOL_WG;
   uint32_t lds_depth = (uint32_t)SOL_LDS_STACK;
@@ -115,14 +120,14 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   // (per-item ray counts).
   P.n_coarse = P.n_items;
   P.fine_count = n - (P.n_chunks - 1u) * SOL_CHUNK;
-  P.stage_at = P.n_items;  // (= n_chunks * slots: right behind the chunk sums)
+  P.stage_at = P.n_chunks * P.n_local_blocks * 64u;  // right behind the chunk sums (of every block, traced or not)
   size_t stage_floats = 0;
   const int fine_tail = s->fine_tail >= 0 ? s->fine_tail : s->fine_tail_auto;
   if (version == 1 && !count && fine_tail > 0) {
-    const uint32_t rest = P.n_local_blocks - std::min(P.n_local_blocks, s->S.n_first);
+    const uint32_t rest = P.n_traced_blocks - std::min(P.n_traced_blocks, s->S.n_first);
     const uint32_t pairs = std::min<uint32_t>(rest, (uint32_t)(((uint64_t)fine_tail * (P.total_threads / 64u) + 3u) / 4u));
     const uint64_t total = items - (uint64_t)pairs * 64u + (uint64_t)pairs * 64u * SOL_CHUNK;
-    if (pairs > 0 && total <= SOL_MAX_ITEMS && items + (uint64_t)pairs * 64u * SOL_CHUNK <= 0xFFFFFFFFull) {
+    if (pairs > 0 && total <= SOL_MAX_ITEMS && (uint64_t)P.stage_at + (uint64_t)pairs * 64u * SOL_CHUNK <= 0xFFFFFFFFull) {
       stage_floats = (size_t)pairs * 64u * SOL_CHUNK * 3u;
       P.n_coarse = (uint32_t)(items - (uint64_t)pairs * 64u);
       P.n_items = (uint32_t)total;
@@ -180,8 +185,10 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
       std::memcpy(&s->S_uploaded, &s->S, sizeof(DevScene));
       s->dscene_valid = true;
     }
-    HIP_TRY(sol_launch_render(version, s->S, s->dscene, P, s->acc, s->partial, s->work, s->spill, s->pool, s->counters, grid, count,
-                              s->has_medium, s->tree_depth > (uint32_t)SOL_LDS_STACK, s->stream));
+    if (P.n_items > 0)
+      HIP_TRY(sol_launch_render(version, s->S, s->dscene, P, s->acc, s->partial, s->work, s->spill, s->pool, s->counters, grid, count,
+                                s->has_medium, s->tree_depth > (uint32_t)SOL_LDS_STACK, s->stream));
+    if (P.n_traced_blocks != P.n_local_blocks) HIP_TRY(sol_launch_fill_background(s->dscene, P, s->partial, s->stream));
   }
   if (s->timing) { HIP_TRY(hipEventRecord(s->ev_stop, s->stream)); s->timed_launches++; }
   s->last_grid = grid;

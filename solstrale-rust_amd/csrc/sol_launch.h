@@ -10,6 +10,7 @@ hipError_t sol_launch_render(int version, const DevScene& S, const DevScene* dS,
                              hipStream_t stream);
 int sol_render_blocks_per_cu(int version, bool count, bool medium, bool strict);
 hipError_t sol_launch_stage_resolve(const DevScene* dS, const RenderParams& P, float* partial, hipStream_t stream);
+hipError_t sol_launch_fill_background(const DevScene* dS, const RenderParams& P, float* partial, hipStream_t stream);
 hipError_t sol_launch_debug_path(const DevScene& S, const RenderParams& P, uint32_t px, uint32_t py, uint32_t s, uint32_t* spill,
                                  float* out, uint32_t max_rows, bool medium, hipStream_t stream);
 // ---- sol_wavefront.hip (-DSOL_AB_KERNELS builds only) ----

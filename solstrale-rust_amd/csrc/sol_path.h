@@ -166,7 +166,7 @@ DEV bool decode_item_ordered(const DevScene& S, const RenderParams& P, uint32_t 
     k = pair / P.n_chunks;
     it.chunk = pair - k * P.n_chunks;
   } else {
-    const uint32_t q = pair - heavy_pairs, rest = P.n_local_blocks - S.n_first;
+    const uint32_t q = pair - heavy_pairs, rest = P.n_traced_blocks - S.n_first;
     it.chunk = q / rest;
     k = S.n_first + (q - it.chunk * rest);
   }

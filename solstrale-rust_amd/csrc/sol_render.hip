@@ -179,6 +179,36 @@ hipError_t sol_launch_stage_resolve(const DevScene* dS, const RenderParams& P, f
   return hipGetLastError();
 }
 
+// Background blocks (include/solstrale_hip.h, SolSceneInfo::background_blocks): the blocks behind the first n_traced_blocks of the work
+// order were proved at scene creation to see nothing but the constant background - every sample of their pixels is a camera ray that
+// comes near no primitive's box, colour = the background (shade_vertex's miss: x = background, c = A * x with A = 1). One thread per
+// (background block, pixel, chunk) writes the chunk sum the render kernel's lane would have written: the same additions in the same order.
+__global__ void __launch_bounds__(256) sol_fill_background_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* __restrict__ partial) {
+  const DevScene& S = *Sp;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t per_chunk = (P.n_local_blocks - P.n_traced_blocks) * 64u;
+  if (i >= per_chunk * P.n_chunks) return;
+  const uint32_t chunk = i / per_chunk, r = i - chunk * per_chunk;
+  const uint32_t k = P.n_traced_blocks + (r >> 6), pin = r & 63u;
+  const uint32_t lb = ldg_u32(S.block_order + k);
+  const uint32_t b = S.block_of_local ? ldg_u32(S.block_of_local + lb) : lb * P.world + P.rank;
+  const uint32_t by = b / P.blocks_x, bx = b - by * P.blocks_x;
+  if (bx * SOL_TILE + (pin & 7u) >= S.width || by * SOL_TILE + (pin >> 3) >= S.height) return;  // padding pixel of an edge block
+  f3 c = mk3(S.bgx, S.bgy, S.bgz);
+  if (S.shader == SOL_SHADER_PATH_TRACING) c = mk3(1.f, 1.f, 1.f) * c;
+  const uint32_t count = min((uint32_t)SOL_CHUNK, P.n_samples - chunk * SOL_CHUNK);
+  f3 sum = mk3(0.f, 0.f, 0.f);
+  for (uint32_t j = 0; j < count; ++j) sum = sum + c;
+  float* o = partial + ((size_t)chunk * (P.n_local_blocks * 64u) + lb * 64u + pin) * 3;
+  o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+}
+hipError_t sol_launch_fill_background(const DevScene* dS, const RenderParams& P, float* partial, hipStream_t stream) {
+  const uint32_t n = (P.n_local_blocks - P.n_traced_blocks) * 64u * P.n_chunks;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(sol_fill_background_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, dS, P, partial);
+  return hipGetLastError();
+}
+
 // Diagnostic: one path (pixel, sample) on one lane, every ray and its closest hit recorded: 12 floats per ray
 // (origin, direction, t, ref bits, dfs bits, depth, 0, 0), then a terminator row (colour in the first 3 floats, -1 in the 4th).
 template <bool MEDIUM, bool STRICT>

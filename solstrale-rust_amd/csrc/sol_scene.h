@@ -51,6 +51,7 @@ struct SolDevOverrides {
   int ploc_radius = 0;           // SOL_PLOC_R (0: the builder's default)
   int split_percent = -1;        // SOL_SPLIT: pre-split budget of the device build in percent of the primitive count (0 off; -1: not set)
   int split_slack = -1;          // SOL_SPLIT_SLACK: levels below the one-primitive cells a plane must lie to be worth a split (-1: not set)
+  int background_blocks = -1;    // SOL_BACKGROUND_BLOCKS: 0 = do not look for background blocks (-1: not set)
   int split_keep = -1;           // SOL_SPLIT_KEEP: keep the splits when the summed box area falls below this percentage (-1: not set)
   int reinsert_rounds = -1;      // SOL_REINSERT: reinsertion rounds of the device build (0 off; -1: not set)
   int reinsert_stride = 0;       // SOL_REINSERT_STRIDE: every n-th node searches per round (0: not set)
@@ -132,6 +133,12 @@ struct SolScene {
   uint32_t last_rounds = 0; int last_version = 0;
   double build_times[4] = {0., 0., 0., 0.};  // sol_scene_build_times
   bool order_enabled = true;         // SOL_OPT_WORK_ORDER
+  // background blocks (solstrale_hip.h SolSceneInfo::background_blocks): per 8x8 block (global index) 1 = proved to see only the
+  // background; n_background_local: how many of them this rank owns - the LAST so many entries of the work order
+  std::vector<uint8_t> background_block;
+  uint32_t n_background = 0, n_background_local = 0, background_pixels = 0;
+  bool background_enabled = true;    // SOL_OPT_BACKGROUND_BLOCKS
+  bool background_in_counted = false;  // (value 2) counted renders skip them too: the counters of exactly what a plain render does
   int order_mode = 2;                // (SOL_ORDER) 1: heavy blocks first only; 2: + cost classes within a chunk
   int max_bpc = 0;                   // SOL_OPT_MAX_BLOCKS_PER_CU (0 = what the occupancy query allows)
   // multi-GPU (sol_comm_init): RCCL communicator of the tile partition and rank 0's receive buffer

@@ -204,9 +204,11 @@ struct RenderParams {
   uint32_t first_sample, n_samples, n_chunks;
   uint32_t rank, world;
   uint32_t n_local_blocks;   // 8x8 blocks owned by this rank
+  uint32_t n_traced_blocks;  // v1: the first so many blocks of the work order are traced; the rest are background blocks (proved at scene
+                             // creation to see nothing but the background), whose sums sol_fill_background_kernel writes
   uint32_t blocks_x;         // blocks per image row
   uint32_t seed_lo, seed_hi;
-  uint32_t n_items;          // n_chunks * n_local_blocks * 64
+  uint32_t n_items;          // n_chunks * n_traced_blocks * 64
   uint32_t total_threads;    // grid * SOL_WG (spill stack stride)
   uint32_t pool_slots;       // pool kernel: path slots per wave (multiple of 64, <= SOL_POOL_MAX)
   uint32_t switch_below;     // v1: a wave leaves the search loop for shading once fewer than this many of its live lanes

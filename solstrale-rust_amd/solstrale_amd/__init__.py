@@ -8,4 +8,4 @@ from . import _abi  # noqa: F401
 from .host import (AlbedoShader, BloomPostProcessor, CameraConfig, HostError, NopPostProcessor, NormalShader, OidnPostProcessor,  # noqa: F401
                    PathTracingShader, RenderConfig, RotationX, RotationY, RotationZ, Scale, Scene, SceneBuilder, SimpleShader,
                    Translation)
-from .device import DeviceError, DeviceScene, comm_unique_id, device_count, record_sizes, world_tree_check  # noqa: F401
+from .device import DeviceError, DeviceScene, background_blocks, comm_unique_id, device_count, record_sizes, world_tree_check  # noqa: F401

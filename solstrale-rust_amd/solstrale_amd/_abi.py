@@ -127,13 +127,13 @@ def _sig(lib, name, res, args):
 
 
 TREE_AUTO, TREE_REF, TREE_SAH8, TREE_SAH16, TREE_SAH64, TREE_DEVICE, TREE_HOST_PROBE = range(7)
-OPT_SWITCH_BELOW, OPT_MAX_BLOCKS_PER_CU, OPT_KERNEL, OPT_WORK_ORDER, OPT_FINE_TAIL, OPT_BALANCED_PARTITION = 1, 2, 3, 4, 5, 6
+OPT_SWITCH_BELOW, OPT_MAX_BLOCKS_PER_CU, OPT_KERNEL, OPT_WORK_ORDER, OPT_FINE_TAIL, OPT_BALANCED_PARTITION, OPT_BACKGROUND_BLOCKS = 1, 2, 3, 4, 5, 6, 7
 UNIQUE_ID_BYTES = 128
 
 
 class SolCreateOptions(C.Structure):
     _fields_ = [("size", C.c_uint32), ("world_tree", C.c_int32), ("no_work_order_probe", C.c_int32), ("split_percent", C.c_int32),
-                ("reinsertion_rounds", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("reinsertion_rounds", C.c_int32), ("no_background_blocks", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class SolSceneInfo(C.Structure):
@@ -141,7 +141,8 @@ class SolSceneInfo(C.Structure):
                 ("tree_fallback", C.c_uint32), ("tree_name", C.c_char * 32), ("tree_note", C.c_char * 192),
                 ("split_references", C.c_uint32), ("split_triangles", C.c_uint32), ("split_area_ratio", C.c_float),
                 ("reinsertion_moves", C.c_uint32), ("reinsertion_area_ratio", C.c_float),
-                ("partition_table", C.c_uint32), ("partition_crc", C.c_uint32), ("strict_triangles", C.c_uint32)]
+                ("partition_table", C.c_uint32), ("partition_crc", C.c_uint32), ("strict_triangles", C.c_uint32),
+                ("background_blocks", C.c_uint32), ("background_pixels", C.c_uint32)]
 
 
 class SolPathStats(C.Structure):
@@ -199,6 +200,7 @@ def load_hip():
     _sig(lib, "sol_scene_create_ex", C.c_int, [C.POINTER(SolSceneDesc), C.c_int, C.POINTER(SolCreateOptions), C.POINTER(P)])
     _sig(lib, "sol_scene_build_times", C.c_int, [P, C.POINTER(C.c_double)])
     _sig(lib, "sol_scene_set_option", C.c_int, [P, C.c_int, C.c_int64])
+    _sig(lib, "sol_background_blocks", C.c_int, [P, C.c_int, P, C.c_size_t, C.POINTER(C.c_uint32)])
     _sig(lib, "sol_scene_info", C.c_int, [P, C.POINTER(SolSceneInfo)])
     _sig(lib, "sol_path_stats", C.c_int, [P, C.POINTER(SolPathStats)])
     _sig(lib, "sol_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)])
@@ -218,7 +220,7 @@ HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol
                "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms",
                "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check", "sol_render_aux", "sol_clear_aux", "sol_read_aux",
                "sol_scene_create_ex", "sol_scene_build_times", "sol_scene_set_option", "sol_scene_info", "sol_path_stats", "sol_comm_unique_id", "sol_comm_init",
-               "sol_comm_destroy", "sol_gather", "sol_comm_self_check", "sol_read_image", "sol_max_samples_per_call"]
+               "sol_comm_destroy", "sol_gather", "sol_comm_self_check", "sol_read_image", "sol_max_samples_per_call", "sol_background_blocks"]
 
 
 def load_host():

@@ -55,19 +55,37 @@ def world_tree_check(scene, use_sah):
     return out.as_dict()
 
 
+def background_blocks(scene, use_sah=0):
+    """Host-only: which 8x8 pixel blocks of `scene` provably see nothing but the background (sol_background_blocks): a bool array
+    [blocks_y, blocks_x]."""
+    import numpy as np
+    lib = _abi.load_hip()
+    bx, by = (scene.width + 7) // 8, (scene.height + 7) // 8
+    flags = (C.c_uint8 * (bx * by))()
+    n = C.c_uint32()
+    rc = lib.sol_background_blocks(scene.desc_ptr, int(use_sah), flags, bx * by, C.byref(n))
+    if rc != 0:
+        raise DeviceError(rc, lib.sol_last_error().decode())
+    out = np.frombuffer(flags, dtype=np.uint8).reshape(by, bx).astype(bool)
+    assert int(out.sum()) == n.value
+    return out
+
+
 class DeviceScene:
     """sol_scene_create .. sol_scene_destroy"""
 
-    def __init__(self, scene, device=0, world_tree=None, no_work_order_probe=False, split_percent=0):
-        """split_percent: SolCreateOptions.split_percent (0: the default budget of the device build's triangle pre-splitting, < 0: none)."""
+    def __init__(self, scene, device=0, world_tree=None, no_work_order_probe=False, split_percent=0, no_background_blocks=False):
+        """split_percent: SolCreateOptions.split_percent (0: the default budget of the device build's triangle pre-splitting, < 0: none);
+        no_background_blocks: SolCreateOptions.no_background_blocks (do not look for blocks that provably see only the background)."""
         self.lib = _abi.load_hip()
         self.scene = scene
         self.h = C.c_void_p()
-        if world_tree is None and not no_work_order_probe and not split_percent:
+        if world_tree is None and not no_work_order_probe and not split_percent and not no_background_blocks:
             rc = self.lib.sol_scene_create(scene.desc_ptr, device, C.byref(self.h))
         else:
             opt = _abi.SolCreateOptions(size=C.sizeof(_abi.SolCreateOptions), world_tree=int(world_tree or 0),
-                                        no_work_order_probe=1 if no_work_order_probe else 0, split_percent=int(split_percent))
+                                        no_work_order_probe=1 if no_work_order_probe else 0, split_percent=int(split_percent),
+                                        no_background_blocks=1 if no_background_blocks else 0)
             rc = self.lib.sol_scene_create_ex(scene.desc_ptr, device, C.byref(opt), C.byref(self.h))
         if rc != 0:
             self.h = None
@@ -116,7 +134,8 @@ class DeviceScene:
                 "tree_fallback": bool(r.tree_fallback), "tree_name": r.tree_name.decode(), "tree_note": r.tree_note.decode(),
                 "split_references": int(r.split_references), "split_triangles": int(r.split_triangles), "split_area_ratio": float(r.split_area_ratio),
                 "reinsertion_moves": int(r.reinsertion_moves), "reinsertion_area_ratio": float(r.reinsertion_area_ratio),
-                "partition_table": int(r.partition_table), "partition_crc": int(r.partition_crc), "strict_triangles": bool(r.strict_triangles)}
+                "partition_table": int(r.partition_table), "partition_crc": int(r.partition_crc), "strict_triangles": bool(r.strict_triangles),
+                "background_blocks": int(r.background_blocks), "background_pixels": int(r.background_pixels)}
 
     def path_stats(self):
         """sol_path_stats of the last counted render: primary hit fraction and the path-length histogram (shares of the samples)."""

@@ -564,6 +564,56 @@ def test_tile_partition_is_bit_identical(world, balanced):
     assert (out == whole).all()
 
 
+def test_background_blocks_change_no_frame():
+    """SolSceneInfo::background_blocks: blocks sol_scene_create proved to see only the background are summed, not traced
+    (tests/test_background_blocks.py checks the proof against the oracle). Frames with and without (SOL_OPT_BACKGROUND_BLOCKS) must be
+    the same bits: whole and partial chunks, a sample range that starts off a chunk edge, a ragged image, a rank's share, single-hit
+    shaders; a counted render always traces everything; and the default build agrees with the oracle on a crop of background and
+    silhouette."""
+    sc = scenes.statue_like(RenderConfig(1283, 717, 40), n_triangles=200000)
+    nb = ((sc.width + 7) // 8) * ((sc.height + 7) // 8)
+    with DeviceScene(sc) as ds:
+        info = ds.info()
+        assert 0.3 * nb < info["background_blocks"] < nb and 0 < info["background_pixels"] <= info["background_blocks"] * 64
+        host = solstrale_background_blocks(sc)
+        assert host.sum() > 0  # (the device tree's proof may find a few blocks more or fewer than a host tree's)
+        for first, n in ((0, 40), (7, 16), (3, 5), (0, 1)):
+            frames = []
+            for on in (1, 0):
+                ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, on)
+                ds.clear(); ds.render(first, n, pu.SEED); frames.append(ds.read())
+            assert (frames[0] == frames[1]).all(), (first, n, int((frames[0] != frames[1]).any(axis=-1).sum()))
+        whole = frames[0]  # (0, 1)
+        ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, 1)
+        ds.clear(); ds.render(0, 8, pu.SEED, counted=True)
+        st = ds.stats()
+        assert st["samples"] == sc.width * sc.height * 8  # counted: nothing skipped
+        counted = ds.read()
+        ds.clear(); ds.render(0, 8, pu.SEED)
+        assert (ds.read() == counted).all()
+        ds.set_partition(3, 8)
+        ds.clear(); ds.render(0, 1, pu.SEED)
+        part = ds.read()
+        owned = part.any(axis=-1)
+        assert owned.sum() > sc.width * sc.height // 10 and (part[owned] == whole[owned]).all()
+    for shader in (AlbedoShader(), NormalShader()):
+        sc2 = scenes.statue_like(RenderConfig(640, 360, 4, shader), n_triangles=50000)
+        with DeviceScene(sc2) as ds:
+            assert ds.info()["background_blocks"] > 0
+            ds.render(0, 4, pu.SEED); a = ds.read()
+            ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, 0); ds.clear(); ds.render(0, 4, pu.SEED)
+            assert (ds.read() == a).all()
+    with DeviceScene(sc, no_background_blocks=True) as ds:
+        assert ds.info()["background_blocks"] == 0
+    assert_parity(sc, 24, rect=(0, 0, 160, 96))        # background only
+    assert_parity(sc, 24, rect=(560, 40, 720, 200))    # the statue's head against the sky
+
+
+def solstrale_background_blocks(sc):
+    from solstrale_amd import background_blocks
+    return background_blocks(sc, 0)
+
+
 def test_device_tonemap_matches_host_arithmetic():
     import torch
     sc = scenes.create_test_scene(RenderConfig(200, 100, 25))
