@@ -35,10 +35,10 @@ struct DeviceSplitInfo {
   uint32_t reinsertion_moves = 0;
   double area_before = 0., area_after = 0.;
 };
-static int device_world_tree(const std::vector<DNode>& bin, uint32_t root_ref, const Box& root_box, float box_pad, const uint32_t counts[3],
-                             const std::vector<DTri>& tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, WideLayout& lay, uint32_t& emin,
-                             DeviceSplitInfo* split_info) {
-  std::vector<SolBuildPrim> prims;
+// The world's primitives as the device builder takes them (each once, in the order of their references): collected once per scene,
+// whatever the number of candidate trees.
+static int collect_build_prims(const std::vector<DNode>& bin, uint32_t root_ref, const Box& root_box, std::vector<SolBuildPrim>& prims) {
+  prims.clear();
   if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) {
     SahBuilder col;
     if (!col.collect(bin, root_ref)) return sol_fail(SOL_EINVAL, "the world's primitives cannot be collected (non-finite box or fewer than two)");
@@ -57,6 +57,13 @@ static int device_world_tree(const std::vector<DNode>& bin, uint32_t root_ref, c
     p.ref = root_ref; p.pad = 0;
     prims.push_back(p);
   }
+  return SOL_OK;
+}
+static int device_world_tree(const std::vector<SolBuildPrim>& prims, const Box& root_box, float box_pad, const uint32_t counts[3],
+                             const std::vector<DTri>& tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, WideLayout& lay, uint32_t& emin,
+                             DeviceSplitInfo* split_info) {
+  const auto t_dbg0 = std::chrono::steady_clock::now();
+  auto dbg = [&](const char* what) { if (split.verbose) std::fprintf(stderr, "[solstrale] device_world_tree: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dbg0).count()); };
   emin = WideBuilder::exponent_min(root_box, box_pad);
   SolDeviceTree dt;
   std::string err;
@@ -64,6 +71,7 @@ static int device_world_tree(const std::vector<DNode>& bin, uint32_t root_ref, c
   if (!sol_build_world_tree_device(prims.data(), (uint32_t)prims.size(), root_box.v, box_pad, emin, counts, have_tris ? tris.data() : nullptr, split, ploc_radius, stream, dt,
                                    err))
     return sol_fail(SOL_EDEVICE, "%s", err.c_str());
+  dbg("device build returned");
   const std::vector<uint32_t> extra_of = std::move(dt.extra_of);
   if (!lay.adopt_device(std::move(dt.nodes), std::move(dt.leaf_refs), dt.new_of_old, dt.depth)) return sol_fail(SOL_EDEVICE, "%s", lay.error.c_str());
   if (split_info) {
@@ -87,6 +95,7 @@ static int device_world_tree(const std::vector<DNode>& bin, uint32_t root_ref, c
       }
     lay.new_of_old[0].resize(counts[0]);  // (a triangle's first reference keeps the triangle's own index)
   }
+  dbg("layout adopted");
   return SOL_OK;
 }
 
@@ -291,7 +300,9 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
     dev_tris = cast_triangles(*d);
     SolSplitOptions sp = split_options(ovr, nullptr);
     sp.want_boxes = true;
-    int rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, dev_tris, sp, ovr.ploc_radius, nullptr, lay, emin_used, &split);
+    std::vector<SolBuildPrim> build_prims;
+    int rc = collect_build_prims(tb.nodes, root_ref, root_box, build_prims);
+    if (!rc) rc = device_world_tree(build_prims, root_box, box_pad, counts, dev_tris, sp, ovr.ploc_radius, nullptr, lay, emin_used, &split);
     if (rc) return rc;
     // a split triangle has several references; each is expected once
     for (uint32_t e = d->n_triangles; e < split.tri_of_ref.size(); ++e) {
@@ -765,12 +776,14 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     if (ovr.ploc_radius > 0) radii = {ovr.ploc_radius};
     else if (opt.world_tree == SOL_TREE_AUTO && ovr.bvh.empty()) radii = {16, 8, 32};
     const uint32_t counts[3] = {d->n_triangles, d->n_spheres, d->n_quads};
-    rc = SOL_OK;
+    std::vector<SolBuildPrim> build_prims;
+    rc = collect_build_prims(tb.nodes, root_ref, root_box, build_prims);
     for (int radius : radii) {
+      if (rc && cands.empty()) break;
       TreeCand c;
       c.name = radii.size() > 1 ? "device" + std::to_string(radius) : "device";
       DeviceSplitInfo si;
-      rc = device_world_tree(tb.nodes, root_ref, root_box, box_pad, counts, tris, split_options(ovr, &opt), radius, s->stream, c.lay, c.emin, &si);
+      rc = device_world_tree(build_prims, root_box, box_pad, counts, tris, split_options(ovr, &opt), radius, s->stream, c.lay, c.emin, &si);
       if (ovr.verbose) std::fprintf(stderr, "[solstrale] device tree (radius %d): pre-splitting %u triangles into %u extra references, box area ratio %.3f%s; %u reinsertion moves\n",
                                     radius, si.split_triangles, si.extra_references, si.area_ratio, si.extra_references ? "" : " (not kept)", si.reinsertion_moves);
       if (!rc) {
