@@ -605,6 +605,16 @@ def test_background_blocks_change_no_frame():
             assert (ds.read() == a).all()
     with DeviceScene(sc, no_background_blocks=True) as ds:
         assert ds.info()["background_blocks"] == 0
+    # a camera that looks away from everything: every block is a background block, no render kernel is launched at all
+    b = SceneBuilder()
+    away = b.finish(b.Bvh([b.Sphere((0., 0., 9.), 1., b.DiffuseLight(5., 5., 5.)), b.Sphere((1., 0., 12.), 1., b.Lambertian(b.SolidColor(.5, .5, .5)))]),
+                    CameraConfig(40., 0., (0., 0., 0.), (0., 0., -1.), (0., 1., 0.)), (.2, .3, .5), RenderConfig(99, 61, 21))
+    with DeviceScene(away) as ds:
+        assert ds.info()["background_blocks"] == 13 * 8 and ds.info()["background_pixels"] == 99 * 61
+        ds.render(0, 21, pu.SEED); a = ds.read()
+        ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, 0); ds.clear(); ds.render(0, 21, pu.SEED)
+        assert (ds.read() == a).all() and np.isfinite(a).all() and (a > 0).all()
+    assert_parity(away, 21)
     assert_parity(sc, 24, rect=(0, 0, 160, 96))        # background only
     assert_parity(sc, 24, rect=(560, 40, 720, 200))    # the statue's head against the sky
 
