@@ -129,7 +129,7 @@ static std::vector<DTri> cast_triangles(const SolSceneDesc& d) {
 // colour and none has to be generated. A ray of the block (generate_path; Camera::get_ray, src/camera.rs:77-89) leaves a point L of
 // the lens - the eye, or eye + lens_radius * (x u + y w) with (x, y) in the unit disc - towards a point T of the focal plane's
 // rectangle of the block's pixels. Both sets are bounded by quadrilaterals (the lens disc's square; the rectangle widened by a whole
-// pixel on every side: the fp32 rounding of generate_path is 10^-7 of that). For a plane normal n all those rays lie in the half
+// pixel on every side plus a bound on the fp32 rounding of generate_path, ordinarily 10^-4 of a pixel). For a plane normal n all those rays lie in the half
 // space n . x <= a with a = max n . L as soon as b = max n . (T - L) <= 0, both maxima taken over the corners (n . (T - L) is linear in
 // T and in L): candidate normals come from the rectangle's edges and the lens corners (and the viewing direction, for what lies behind
 // the camera), built from slightly LARGER quadrilaterals so that the check b <= 0 on the real ones holds with room to spare, and a
@@ -159,6 +159,15 @@ static void find_background_blocks(const WideLayout& L, uint32_t emin, const DCa
     lens[k] = V{org.x + (lu.x * sx + lw.x * sy) * r, org.y + (lu.y * sx + lw.y * sy) * r, org.z + (lu.z * sx + lw.z * sy) * r};
     lens_wide[k] = V{org.x + (lu.x * sx + lw.x * sy) * rw, org.y + (lu.y * sx + lw.y * sy) * rw, org.z + (lu.z * sx + lw.z * sy) * rw};
   }
+  // generate_path forms T and the direction T - L in fp32: each component errs by a few ulps of the largest term. In pixels of the
+  // focal plane that is 10^-4 for an ordinary camera; a camera a million units from the origin with a narrow field of view is another
+  // matter - the margin grows with it, and beyond three pixels the proof is not attempted.
+  const double norm_max = std::max(std::max(std::fabs(ll.x), std::max(std::fabs(ll.y), std::fabs(ll.z))) + std::max(std::fabs(hh.x), std::max(std::fabs(hh.y), std::fabs(hh.z))) +
+                                   std::max(std::fabs(vv.x), std::max(std::fabs(vv.y), std::fabs(vv.z))), std::max(std::fabs(org.x), std::max(std::fabs(org.y), std::fabs(org.z)))) + (double)cam.lens_radius * 2.;
+  const double pixel = std::min(std::sqrt(dot(hh, hh)) / (double)(width - 1), std::sqrt(dot(vv, vv)) / (double)(height - 1));
+  const double rounding_px = pixel > 0. ? 8.0 * 1.1920929e-7 * norm_max / pixel : 1e300;
+  if (!(rounding_px < 3.0)) return;
+  const double grow = 1.0 + rounding_px;
   struct Plane { V n; double a; };
   std::vector<uint32_t> stack;
   for (uint32_t by = 0; by < by_n; ++by)
@@ -172,8 +181,8 @@ static void find_background_blocks(const WideLayout& L, uint32_t emin, const DCa
         for (int k = 0; k < 4; ++k) t[k] = V{ll.x + hh.x * cu[k] + vv.x * cv[k], ll.y + hh.y * cu[k] + vv.y * cv[k], ll.z + hh.z * cu[k] + vv.z * cv[k]};
       };
       V T[4], Tw[4];
-      corners(1.0, T);
-      corners(2.0, Tw);
+      corners(grow, T);
+      corners(grow + 1.0, Tw);
       Plane plane[17];
       int n_planes = 0;
       // keeps the candidate n (pointing AWAY from the rays) if every ray of the block provably stays in n . x <= a

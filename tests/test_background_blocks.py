@@ -91,3 +91,24 @@ def test_a_silhouette_block_is_traced():
         for dx in range(-2, 3):
             near |= np.roll(np.roll(tb, dy, axis=0), dx, axis=1)
     assert f[~near].all()
+
+
+def _far_scene(offset, rc):
+    b = SceneBuilder()
+    cam = CameraConfig(2., 0., (offset, 0., 500.), (offset, 0., 0.), (0., 1., 0.))
+    light = b.DiffuseLight(5., 5., 5.)
+    world = [b.Sphere((offset, 0., 0.), 3., light), b.Sphere((offset + 2., 1., -20.), 2.5, b.Lambertian(b.SolidColor(.5, .5, .5)))]
+    return b.finish(b.Bvh(world), cam, (.2, .3, .5), rc)
+
+
+def test_a_camera_far_from_the_origin_widens_the_margin_or_gives_up():
+    """generate_path forms the ray in fp32: far from the origin its direction errs by more than the pixel the proof allows for. The margin
+    grows with that bound (10 000 units away: a tenth of a pixel) and beyond three pixels no block is flagged (2 000 000 away, 2 degrees
+    of view: the fp32 rays are ~30 pixels off - the float oracle, like the device, renders what those rays see)."""
+    rc = RenderConfig(256, 256, 6)
+    near = _far_scene(1e4, rc)
+    f = background_blocks(near, 0)
+    assert f.any() and not f[16, 16]
+    img, _ = orc.render(near, 0, 6, pu.SEED, real=orc.ORC_F32)
+    assert (img[_pixel_mask(f, near)] == _background_sum(near, 6)).all()
+    assert not background_blocks(_far_scene(2e6, rc), 0).any()
