@@ -615,6 +615,10 @@ def test_background_blocks_change_no_frame():
         ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, 0); ds.clear(); ds.render(0, 21, pu.SEED)
         assert (ds.read() == a).all() and np.isfinite(a).all() and (a > 0).all()
     assert_parity(away, 21)
+    # cameras far from the origin (the fp32 rounding of the camera ray is part of the proof's margin; tests/test_background_blocks.py)
+    from test_background_blocks import _far_scene
+    for offset in (1e4, 2e6):
+        assert_parity(_far_scene(offset, RenderConfig(256, 256, 8)), 8)
     assert_parity(sc, 24, rect=(0, 0, 160, 96))        # background only
     assert_parity(sc, 24, rect=(560, 40, 720, 200))    # the statue's head against the sky
 
