@@ -219,7 +219,9 @@ static inline void sol_triangle_rotated(const SolTriangle* t, int k, double v0[3
  * counts a triangle hit only if the ray's point o + t*d and the triangle's point v0 + u*e1 + v*e2 agree within 0.8 pads in
  * every coordinate: an accepted hit then lies inside every box around its part of the triangle, whatever the tree. Both sides decide
  * with THIS function. */
+#ifndef SOL_NEEDLE_ASPECT
 #define SOL_NEEDLE_ASPECT 32.0
+#endif
 #ifndef SOL_NEEDLE_PAD
 #define SOL_NEEDLE_PAD 4.0f /* such scenes' box pad, in thin pads (S * 2^-20); the rule's tolerance is 0.8 of it */
 #endif
