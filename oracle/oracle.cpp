@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -256,7 +257,9 @@ template <typename R> struct Scene {
       if (b) for (int j = 0; j < 6; ++j) take(b->v[j]);
       for (int j = 0; j < 3; ++j) take(d.camera.origin[j]);
       pad = (R)(S * (1.0f / 1048576.0f));
-      strict_tri = sol_scene_has_needles(&d) != 0;
+      // (ORC_NO_NEEDLE_RULE: a diagnostic switch of this checker only - "plain fp32" for tests/tools/needle_bias.py, which measures what the
+      // rule does to the image; the device has no such switch and the parity tests never set it)
+      strict_tri = sol_scene_has_needles(&d) != 0 && !std::getenv("ORC_NO_NEEDLE_RULE");
       if (strict_tri) pad = (R)(S * (SOL_NEEDLE_PAD / 1048576.0f));  // (the consistency tolerance of hit_triangle is 0.8 of it)
     }
     box_pad = pad;
