@@ -543,9 +543,11 @@ __global__ void __launch_bounds__(BT) k_refit(uint32_t n_leaves, const uint32_t*
   double sum = 0.;
   int steps = 0;
   while (m != NONE && ++steps < 4096) {
-    __threadfence();
+    // release (the boxes this thread wrote are visible before its arrival is) / acquire (the second to arrive sees the first one's boxes): the
+    // two halves of what a __threadfence() on either side did in full, twice (C3: 1.33 -> 0.75 ms per launch, 27 launches per scene)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (atomicAdd(&arrived[m], 1u) == 0u) break;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const float *ba = nbox + (size_t)left[m] * 6, *bb = nbox + (size_t)right[m] * 6;
     float* bo = nbox + (size_t)m * 6;
     for (int k = 0; k < 6; k += 2) { bo[k] = fminf(ba[k], bb[k]); bo[k + 1] = fmaxf(ba[k + 1], bb[k + 1]); }
@@ -588,9 +590,9 @@ __global__ void __launch_bounds__(BT) k_collapse_cost(uint32_t n_leaves, const u
   }
   uint32_t m = parent[i];
   while (m != NONE) {
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (as in k_refit: this thread's table first, then its arrival)
     if (atomicAdd(&arrived[m], 1u) == 0u) return;  // the sibling's thread will do this node
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const Dp dl = dp[left[m]], dr = dp[right[m]];
     Dp e;
     float dist[8];
