@@ -482,6 +482,19 @@ def worker(args):
         fence()
         gather_ms = round(coord.max(time.perf_counter() - tg) * 1e3, 3)
     last_call_spp = spp - (spp - 1) // max_spp_call * max_spp_call
+    # The same job with EVERY sample generated and traced (SOL_OPT_BACKGROUND_BLOCKS 0), timed the same way after the timed region of
+    # `value` (one warm-up, two steps; N = 1 only): so that the line carries both figures and nobody has to take the skipped samples on trust.
+    value_all_traced = None
+    if world == 1 and tree_info["background_blocks"] > 0:
+        ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, 0)
+        step()
+        fence()
+        ta = time.perf_counter()
+        for _ in range(2):
+            step()
+        fence()
+        value_all_traced = float(w) * h * spp / ((time.perf_counter() - ta) / 2) / 1e6
+        ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, 1)
 
     # ---- counters: exact per-sample algorithmic bytes and rays from a counter-enabled run of the same kernels ----
     frame = ds.read_image() if (rank == 0 and args.rehearse) else None  # the gathered frame of the last step
@@ -530,6 +543,7 @@ def worker(args):
             "rays_per_sample": round(rays_per_sample, 4),
             "traced_rays_per_sample": round(traced_rays_per_sample, 4),
             "background_blocks": {"blocks": tree_info["background_blocks"], "sample_fraction": round(background_samples / st["samples"], 4),
+                                  "value_with_every_sample_traced": None if value_all_traced is None else round(value_all_traced, 2),
                                   "note": "8x8 pixel blocks of which sol_scene_create proved that no camera ray of theirs, whatever the jitter, comes near a "
                                           "primitive's box: every sample is the background colour, summed in the reference's order without being traced "
                                           "(frames bit-identical with SOL_OPT_BACKGROUND_BLOCKS 0; SOL_BACKGROUND_BLOCKS=0 in the environment switches the proof off). "
