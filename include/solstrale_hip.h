@@ -184,8 +184,10 @@ typedef struct SolSceneDesc {
  * edge lengths at v0. The fp32 records (device, and the oracle's float instantiation) therefore start at the vertex OPPOSITE THE LONGEST
  * EDGE: a cyclic rotation (v0, v1, v2) -> (v_k, v_k+1, v_k+2) - same winding, same normal, same set of points; the texture
  * coordinates rotate along, so the interpolated values are the same numbers up to rounding. k = 0 unless another start is strictly
- * better; a triangle that is a LIGHT keeps the reference's order (Triangle::random_direction samples the parallelogram at v0,
- * triangle.rs:114-117). For a strip-shaped needle of aspect 300:1 this takes the test's noise down by that factor. f64 is untouched. */
+ * better. A triangle that is a LIGHT is INTERSECTED through its rotated record like any other and SAMPLED in the reference's own
+ * frame (Triangle::random_direction draws from the parallelogram at the first vertex, triangle.rs:114-117 - a set that depends on the
+ * start): both sides keep the unrotated (v0, v0v1, v0v2) of every triangle light for that. For a strip-shaped needle of aspect 300:1
+ * the rotation takes the test's noise down by that factor. f64 is untouched. */
 static inline int sol_triangle_rotation(const SolTriangle* t) {
   const double a[3] = {t->v0v1[0], t->v0v1[1], t->v0v1[2]}, b[3] = {t->v0v2[0], t->v0v2[1], t->v0v2[2]};
   const double c[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};

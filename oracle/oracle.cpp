@@ -226,6 +226,8 @@ template <typename R> struct Scene {
   std::vector<Node> nodes; std::vector<Sph> spheres; std::vector<Qd> quads; std::vector<Tri> tris;
   std::vector<Med> meds; std::vector<Mat> mats; std::vector<Tex> texs; const uint8_t* texels = nullptr;
   std::vector<uint32_t> lights;
+  struct Frame { V3<R> v0, e1, e2; };
+  std::vector<Frame> light_frames;  // by light index: a triangle light's (v0, v0v1, v0v2) in the REFERENCE's vertex order (what random_direction samples)
   uint32_t root = 0, width = 0, height = 0, shader = 0, max_depth = 0;
   V3<R> background;
   const float* env = nullptr; uint32_t env_w = 0, env_h = 0; R env_scale = 1;  // EXTENSION (SolSceneDesc, abi_version >= 2)
@@ -283,14 +285,11 @@ template <typename R> struct Scene {
       quads[i] = {cv(s.q), cv(s.u), cv(s.v), cv(s.normal), cv(s.w), (R)s.d, (R)s.area, s.material, s.dfs_index};
     }
     tris.resize(d.n_triangles);
-    std::vector<uint8_t> is_light(d.n_triangles, 0);
-    for (uint32_t i = 0; i < d.n_lights; ++i)
-      if (SOL_REF_KIND(d.lights[i]) == SOL_REF_TRIANGLE && SOL_REF_INDEX(d.lights[i]) < d.n_triangles) is_light[SOL_REF_INDEX(d.lights[i])] = 1;
     for (uint32_t i = 0; i < d.n_triangles; ++i) {
       const SolTriangle& s = d.triangles[i];
-      // fp32 contract (solstrale_hip.h, sol_triangle_rotation): the float record starts at the vertex opposite the longest edge; f64 and
-      // light triangles keep the reference's order
-      const int k = (sizeof(R) == 4 && !is_light[i]) ? sol_triangle_rotation(&s) : 0;
+      // fp32 contract (solstrale_hip.h, sol_triangle_rotation): the float record starts at the vertex opposite the longest edge; f64
+      // keeps the reference's order (a triangle LIGHT is sampled in the reference's frame either way: light_frames below)
+      const int k = sizeof(R) == 4 ? sol_triangle_rotation(&s) : 0;
       double v0[3], e1[3], e2[3];
       int uo[3];
       sol_triangle_rotated(&s, k, v0, e1, e2, uo);
@@ -312,6 +311,12 @@ template <typename R> struct Scene {
     }
     texels = d.texels;
     lights.assign(d.lights, d.lights + d.n_lights);
+    light_frames.assign(d.n_lights, Frame{});
+    for (uint32_t i = 0; i < d.n_lights; ++i)
+      if (SOL_REF_KIND(d.lights[i]) == SOL_REF_TRIANGLE && SOL_REF_INDEX(d.lights[i]) < d.n_triangles) {
+        const SolTriangle& s = d.triangles[SOL_REF_INDEX(d.lights[i])];
+        light_frames[i] = {cv(s.v0), cv(s.v0v1), cv(s.v0v2)};
+      }
   }
 };
 
@@ -572,7 +577,7 @@ template <typename R> struct Tracer {
     }
     return 0;  // the reference panics for non-light shapes (hittable/mod.rs:28-35); unreachable by construction
   }
-  V3<R> light_random_direction(uint32_t ref, const V3<R>& origin) {
+  V3<R> light_random_direction(uint32_t ref, uint32_t light_index, const V3<R>& origin) {
     uint32_t idx = SOL_REF_INDEX(ref);
     switch (SOL_REF_KIND(ref)) {
       case SOL_REF_QUAD: {
@@ -580,10 +585,10 @@ template <typename R> struct Tracer {
         R r1 = rnd(); R r2 = rnd();
         return Q.q + Q.u * r1 + Q.v * r2 - origin;
       }
-      case SOL_REF_TRIANGLE: {
-        const auto& T = sc.tris[idx];
+      case SOL_REF_TRIANGLE: {  // triangle.rs:114-117: the parallelogram at the reference's first vertex
+        const auto& F = sc.light_frames[light_index];
         R r1 = rnd(); R r2 = rnd();
-        return T.v0 + T.e1 * r1 + T.e2 * r2 - origin;
+        return F.v0 + F.e1 * r1 + F.e2 * r2 - origin;
       }
       case SOL_REF_SPHERE: {
         const auto& S = sc.spheres[idx];
@@ -606,7 +611,7 @@ template <typename R> struct Tracer {
   }
   V3<R> container_pdf_generate(const V3<R>& origin) {  // pdf.rs:98-101
     uint32_t idx = rnd_index((uint32_t)sc.lights.size());
-    return light_random_direction(sc.lights[idx], origin);
+    return light_random_direction(sc.lights[idx], idx, origin);
   }
 
   // ---- scatter (material/mod.rs) -----------------------------------------------------------------------------

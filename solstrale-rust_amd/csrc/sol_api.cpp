@@ -218,7 +218,7 @@ void sol_scene_destroy(SolScene* s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   sol_comm_destroy(s);
-  void* ptrs[] = {s->leaf_refs, s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->env, s->lights,
+  void* ptrs[] = {s->leaf_refs, s->nodes, s->wides, s->tris, s->tri_shade, s->quads, s->spheres, s->mediums, s->mats, s->texs, s->texels, s->env, s->lights, s->light_tri,
                   s->acc_own, s->partial, s->image, s->rgb8, s->work, s->spill, s->counters, s->pool, s->queue, s->wf_ctr,
                   s->bloom_a, s->bloom_b, s->bloom_w, s->aux[0], s->aux[1], s->dscene, s->order_dev, s->block_of_local_dev, s->slot_of_block};
   if (s->wf_ctr_host) hipHostFree(s->wf_ctr_host);

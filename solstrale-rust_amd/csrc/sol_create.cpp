@@ -100,28 +100,30 @@ static int device_world_tree(const std::vector<SolBuildPrim>& prims, const Box& 
 }
 
 // A triangle's fp32 intersect record: starts at the vertex opposite the longest edge (fp32 arithmetic contract, solstrale_hip.h
-// sol_triangle_rotation; the oracle's float instantiation makes the same choice), except for lights, which keep the reference's order.
-// uv_of = which of {uv0, uv1, uv2} belongs to the record's three vertices.
-static void cast_triangle(const SolTriangle& t, bool is_light, DTri& o, int uv_of[3]) {
+// sol_triangle_rotation; the oracle's float instantiation makes the same choice); `reference_order`: as the reference lists the vertices -
+// the frame a triangle LIGHT is sampled in (DevScene::light_tri). uv_of = which of {uv0, uv1, uv2} belongs to the record's three vertices.
+static void cast_triangle(const SolTriangle& t, bool reference_order, DTri& o, int uv_of[3]) {
   double v0[3], e1[3], e2[3];
-  sol_triangle_rotated(&t, is_light ? 0 : sol_triangle_rotation(&t), v0, e1, e2, uv_of);
+  sol_triangle_rotated(&t, reference_order ? 0 : sol_triangle_rotation(&t), v0, e1, e2, uv_of);
   o.v0x = (float)v0[0]; o.v0y = (float)v0[1]; o.v0z = (float)v0[2];
   o.e1x = (float)e1[0]; o.e1y = (float)e1[1]; o.e1z = (float)e1[2];
   o.e2x = (float)e2[0]; o.e2y = (float)e2[1]; o.e2z = (float)e2[2];
   o.dfs = t.dfs_index; o.mat = t.material; o.area = (float)t.area;
 }
-static std::vector<uint8_t> light_triangles(const SolSceneDesc& d) {
-  std::vector<uint8_t> is_light(d.n_triangles, 0);
+// the sampling frames of the triangle lights, by light index (entries of other lights stay zero)
+static std::vector<DTri> light_triangle_frames(const SolSceneDesc& d) {
+  std::vector<DTri> frames(std::max<uint32_t>(1u, d.n_lights), DTri{});
+  int uv_of[3];
   for (uint32_t i = 0; i < d.n_lights; ++i)
-    if (SOL_REF_KIND(d.lights[i]) == SOL_REF_TRIANGLE && SOL_REF_INDEX(d.lights[i]) < d.n_triangles) is_light[SOL_REF_INDEX(d.lights[i])] = 1;
-  return is_light;
+    if (SOL_REF_KIND(d.lights[i]) == SOL_REF_TRIANGLE && SOL_REF_INDEX(d.lights[i]) < d.n_triangles)
+      cast_triangle(d.triangles[SOL_REF_INDEX(d.lights[i])], true, frames[i], uv_of);
+  return frames;
 }
 // the triangles' vertices as the device will hold them (what pre-splitting clips)
 static std::vector<DTri> cast_triangles(const SolSceneDesc& d) {
   std::vector<DTri> tris(d.n_triangles);
-  const std::vector<uint8_t> is_light = light_triangles(d);
   int uv_of[3];
-  for (uint32_t i = 0; i < d.n_triangles; ++i) cast_triangle(d.triangles[i], is_light[i] != 0, tris[i], uv_of);
+  for (uint32_t i = 0; i < d.n_triangles; ++i) cast_triangle(d.triangles[i], false, tris[i], uv_of);
   return tris;
 }
 // Background blocks (include/solstrale_hip.h, SolSceneInfo::background_blocks): the 8x8 pixel blocks of which it can be PROVED that
@@ -572,12 +574,11 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   // ---- primitives (plain casts) ----
   std::vector<DTri> tris(d->n_triangles);
   std::vector<DTriShade> tshade(d->n_triangles);
-  const std::vector<uint8_t> tri_is_light = light_triangles(*d);
   for (uint32_t i = 0; i < d->n_triangles; ++i) {
     const SolTriangle& t = d->triangles[i];
     if (!mat_ok(t.material)) return sol_fail(SOL_EINVAL, "triangle %u: bad material", i);
     int uo[3];
-    cast_triangle(t, tri_is_light[i] != 0, tris[i], uo);
+    cast_triangle(t, false, tris[i], uo);
     const float* uvs[3] = {t.uv0, t.uv1, t.uv2};
     DTriShade& s = tshade[i];
     s.nx = (float)t.normal[0]; s.ny = (float)t.normal[1]; s.nz = (float)t.normal[2]; s.mat = t.material;
@@ -894,6 +895,8 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   S.rzmin = root_box.v[4]; S.rzmax = root_box.v[5];
   S.width = d->width; S.height = d->height; S.shader = d->shader_kind; S.max_depth = d->max_depth;
   S.sphere_slack = box_pad * 0.5f;
+  if ((rc = sol_upload(light_triangle_frames(*d), &s->light_tri))) return rc;
+  S.light_tri = s->light_tri;
   S.tri_delta = sol_scene_has_needles(d) ? box_pad * 0.8f : 0.0f;
   s->strict_triangles = S.tri_delta > 0.0f;
   S.env = nullptr; S.env_w = S.env_h = 0; S.env_scale = 1.0f;

@@ -94,7 +94,7 @@ struct SolScene {
   uint32_t* leaf_refs = nullptr;
   DNode* nodes = nullptr; DWide* wides = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
   DSphere* spheres = nullptr; DMedium* mediums = nullptr; DMat* mats = nullptr; DTex* texs = nullptr;
-  uint8_t* texels = nullptr; uint32_t* lights = nullptr; float* env = nullptr;
+  uint8_t* texels = nullptr; uint32_t* lights = nullptr; float* env = nullptr; DTri* light_tri = nullptr;
   float* acc_own = nullptr; float* acc = nullptr; size_t acc_floats = 0;
   float* aux[2] = {nullptr, nullptr}; size_t aux_floats = 0;
   std::vector<uint32_t> block_cost;  // per 8x8 block (global index): rays of its longest item in the cost probe; empty: no ordering

@@ -148,7 +148,7 @@ DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Co
   return 0.0f;
 }
 // Hittable::random_direction of quad (quad.rs:145-148), triangle (triangle.rs:114-117), sphere (sphere.rs:58-62,142-153)
-DEV f3 light_random_direction(const DevScene& S, uint32_t ref, f3 origin, Rng& rng) {
+DEV f3 light_random_direction(const DevScene& S, uint32_t ref, uint32_t light_index, f3 origin, Rng& rng) {
   const uint32_t kind = SOL_REF_KIND(ref), idx = SOL_REF_INDEX(ref);
   if (kind == SOL_REF_QUAD) {
     const DQuad Q = ldg_rec(S.quads + idx);
@@ -156,7 +156,7 @@ DEV f3 light_random_direction(const DevScene& S, uint32_t ref, f3 origin, Rng& r
     return mk3(Q.qx, Q.qy, Q.qz) + mk3(Q.ux, Q.uy, Q.uz) * r1 + mk3(Q.vx, Q.vy, Q.vz) * r2 - origin;
   }
   if (kind == SOL_REF_TRIANGLE) {
-    const DTri T = ldg_rec(S.tris + idx);
+    const DTri T = ldg_rec(S.light_tri + light_index);  // the reference's frame, not the rotated intersect record (sol_types.h)
     float r1 = rnd(rng), r2 = rnd(rng);
     return mk3(T.v0x, T.v0y, T.v0z) + mk3(T.e1x, T.e1y, T.e1z) * r1 + mk3(T.e2x, T.e2y, T.e2z) * r2 - origin;
   }
@@ -180,7 +180,7 @@ DEV float container_pdf_value(const DevScene& S, f3 origin, f3 dir, Counters& cn
 }
 DEV f3 container_pdf_generate(const DevScene& S, f3 origin, Rng& rng) {  // pdf.rs:98-101
   uint32_t i = rnd_index(rng, S.n_lights);  // (the draw is consumed also when there is one light: same stream as the oracle)
-  return light_random_direction(S, S.n_lights == 1u ? S.light0 : ldg_u32(S.lights + i), origin, rng);
+  return light_random_direction(S, S.n_lights == 1u ? S.light0 : ldg_u32(S.lights + i), S.n_lights == 1u ? 0u : i, origin, rng);
 }
 DEV f3 random_in_unit_sphere(Rng& rng) {  // vec3.rs:380-392 (bound never reached: (1-pi/6)^80)
   f3 p = mk3(0.f, 0.f, 0.f);

@@ -198,6 +198,10 @@ struct DevScene {
   // Scenes with needle triangles (solstrale_hip.h, sol_scene_has_needles): tolerance of the triangle hit's consistency rule, 0.8
   // box pads; 0: the scene has none and the rule is off. (Last: the fields above keep the offsets the scalar loads were tuned around.)
   float tri_delta;
+  // Triangle LIGHTS are sampled in the reference's own frame - Triangle::random_direction draws from the parallelogram at the FIRST
+  // vertex (triangle.rs:114-117), which is not the vertex the intersect record starts at (solstrale_hip.h, sol_triangle_rotation):
+  // light_tri[i] = (v0, v0v1, v0v2) of light i in the reference's order when light i is a triangle (a DTri whose other fields are unused).
+  const DTri* light_tri;
 };
 
 struct RenderParams {

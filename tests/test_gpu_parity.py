@@ -348,6 +348,19 @@ def test_fp32_records_start_opposite_the_longest_edge():
     assert abs(img.mean() - f64.mean()) < 3e-3 * f64.mean(), (img.mean(), f64.mean())
 
 
+@pytest.mark.parametrize("aspect", [20, 300, 2000])
+def test_needle_shaped_lights(aspect):
+    """A strip light of two needle triangles (tests/test_fp32_contract.py): the device agrees with the float oracle pixel by pixel and
+    with the double one in the mean - its hits go through the rotated records, its samples come from the reference's frame
+    (DevScene::light_tri)."""
+    from test_fp32_contract import strip_light_scene
+    sc = strip_light_scene(aspect, RenderConfig(96, 64, 128, PathTracingShader(8)))
+    assert_parity(sc, 128)
+    f64, _ = orc.render(sc, 0, 128, pu.SEED, real=orc.ORC_F64)
+    img = gpu_render(sc, 128)
+    assert abs(img.mean() - f64.mean()) < 1e-4 * f64.mean(), (aspect, img.mean(), f64.mean())
+
+
 def test_uv_wrapping():
     # triangle UVs outside [0,1] incl. negative (tests/scenes.rs:196-230)
     assert_parity(scenes.create_uv_scene(RenderConfig(128, 128, 8)), 8)
