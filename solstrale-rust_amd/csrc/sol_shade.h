@@ -129,7 +129,8 @@ DEV float light_pdf_value(const DevScene& S, uint32_t ref, f3 origin, f3 dir, Co
     if (COUNT) cnt.triangle_tests++;
     float t, u, v;
     if (!tri_test(T, origin, dir, RAY_MIN_F, inf, t, u, v)) return 0.0f;
-    if (STRICT && !tri_hit_consistent(T, origin, dir, t, u, v, S.tri_delta)) return 0.0f;  // (scenes with needle triangles: sol_trace.h)
+    // (no consistency rule here, in scenes with needle triangles either: the rule makes SEARCH results independent of the tree, and this
+    // is a one-primitive test; a refused hit would report pdf 0 for a direction that light_random_direction generates densely - oracle.cpp)
     f3 n = mk3(Ts.nx, Ts.ny, Ts.nz);
     if (!(dot3(dir, n) < 0.0f)) n = neg3(n);
     float ds = t * t * len2(dir);
