@@ -451,6 +451,13 @@ template <typename R> struct Tracer {
     V3<R> bi_tangent = n.cross(tangent);
     bool front = r.direction.dot(normal) < (R)0;
     if (!front) normal = normal.neg();
+    // fp32 contract (fifth rule): the hit POINT of a sphere is put back on the sphere. The reference's quadratic in single
+    // precision loses the digits of a distant origin - a camera ray from 800 units away reports t a few thousandths off, its point that
+    // deep inside (or outside) a sphere of radius 5 -, and a scattered ray that starts inside re-hits the same sphere from within at
+    // t > 0.001: one more bounce, darker (Cornell box + 10 000 spheres: 7 % more rays, the frame 8 % darker than f64). The direction
+    // centre -> point is good to an ulp whatever t is; the point at distance r along it is what f64 computes to 13 digits. Normal, uv and
+    // tangents are taken from the point as computed, as before. f64: nothing changes.
+    if (sizeof(R) == 4) hp = S.center + n * (S.radius / n.length());
     out = {root, hp, {tangent, bi_tangent, normal}, uv, front, S.mat};
     return true;
   }

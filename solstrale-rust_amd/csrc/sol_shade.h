@@ -69,6 +69,9 @@ DEV void build_surface(const DevScene& S, f3 o, f3 d, const Hit& h, const Rng& r
     const DSphere Sp = ldg_rec(S.spheres + idx);
     f3 n = sf.p - mk3(Sp.cx, Sp.cy, Sp.cz);
     f3 normal = unit3(n);
+    // fp32 contract, fifth rule (oracle.cpp hit_sphere): the hit point goes back onto the sphere - t of the fp32 quadratic is off by
+    // thousandths for distant origins, the direction centre -> point is not; normal, uv and tangents stay as computed from the raw point
+    sf.p = mk3(Sp.cx, Sp.cy, Sp.cz) + n * (Sp.radius / len3(n));
     sf.mat = Sp.mat;
     if (ldg_u32(&S.mats[Sp.mat].flags) & DMAT_NEEDS_UV) {  // uv and tangents are consumed only by image textures
       float theta = acos_r(-normal.y);

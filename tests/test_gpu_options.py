@@ -77,11 +77,18 @@ def test_fine_tail_keeps_every_frame(size, make):
 def test_creation_without_the_work_order_probe():
     """`no_work_order_probe` (an EverySample preview that must start at once): no counted 4-spp probe of the frame at creation."""
     sc = scenes.statue_like(RenderConfig(480, 270, 16), n_triangles=60000)
+    # (what the probe leaves behind: per-block costs, which the balanced partition needs - without them the option falls back to b % world.
+    # Its time, a few ms of the creation, is not asserted: a first launch in a fresh process costs more than the probe.)
     with DeviceScene(sc) as ds:
-        want, with_probe = _frame(ds), ds.build_times()["probes"]
+        want = _frame(ds)
+        ds.set_option(_abi.OPT_BALANCED_PARTITION, 1)
+        ds.set_partition(0, 2)
+        assert ds.info()["partition_table"] == 1
     with DeviceScene(sc, no_work_order_probe=True) as ds:
         assert (_frame(ds) == want).all()
-        assert ds.build_times()["probes"] < with_probe
+        ds.set_option(_abi.OPT_BALANCED_PARTITION, 1)
+        ds.set_partition(0, 2)
+        assert ds.info()["partition_table"] == 0
 
 
 def test_bad_creation_options_are_rejected():
