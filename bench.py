@@ -101,6 +101,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic = null, no roofline_valu)")
+    ap.add_argument("--no-all-traced", action="store_true", help="skip the extra steps that time the job with every sample traced (background_blocks."
+                    "value_with_every_sample_traced = null); the counter passes use it: they must see the timed launch and nothing else")
     ap.add_argument("--pmc-spp", type=int, default=64)
     ap.add_argument("--no-build", action="store_true", help="do not run the build step (use under rocprofv3: no child processes)")
     ap.add_argument("--rehearse", action="store_true",
@@ -301,7 +303,7 @@ def pmc_passes(args, spp):
             d = os.path.join(out, grp[0])
             cmd = [rocprof, "--pmc"] + grp + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                                               os.path.abspath(__file__), "--workload", args.workload, "--spp", str(spp), "--steps", "1",
-                                              "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-build"]
+                                              "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-build", "--no-all-traced"]
             if args.hdri:
                 cmd += ["--hdri"]
             if args.camera_preset != "default":
@@ -485,7 +487,7 @@ def worker(args):
     # The same job with EVERY sample generated and traced (SOL_OPT_BACKGROUND_BLOCKS 0), timed the same way after the timed region of
     # `value` (one warm-up, two steps; N = 1 only): so that the line carries both figures and nobody has to take the skipped samples on trust.
     value_all_traced = None
-    if world == 1 and tree_info["background_blocks"] > 0:
+    if world == 1 and tree_info["background_blocks"] > 0 and not args.no_all_traced:
         ds.set_option(_abi.OPT_BACKGROUND_BLOCKS, 0)
         step()
         fence()

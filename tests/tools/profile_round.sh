@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 if [ "$mode" = "stats" ]; then
   python3 bench.py --steps 3 --warmup 1 > $out/${tag}_bench.json 2> $out/${tag}_bench.err || exit 1
   tail -c 600 $out/${tag}_bench.json
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-build \
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-build --no-all-traced \
       > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof.err) || exit 1
   find $out/${tag}_prof -name '*kernel_stats.csv' -exec cp {} $out/${tag}_kernel_stats.csv \;
   head -5 $out/${tag}_kernel_stats.csv
@@ -24,7 +24,7 @@ else
     if [ -n "$3" ] && [[ "$grp" != *"$3"* ]]; then continue; fi
     name=$(echo $grp | tr ' ' '+')
     echo "== $grp"
-    (cd /tmp && timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/${tag}_pmc/$name -- python3 $OLDPWD/bench.py --spp 64 --steps 1 --warmup 0 --no-cpu-baseline --no-pmc --no-build \
+    (cd /tmp && timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/${tag}_pmc/$name -- python3 $OLDPWD/bench.py --spp 64 --steps 1 --warmup 0 --no-cpu-baseline --no-pmc --no-build --no-all-traced \
         > $out/${tag}_pmc_$name.log 2>&1) || { echo "pass failed: $grp"; tail -3 $out/${tag}_pmc_$name.log; }
   done
 fi
