@@ -6,7 +6,9 @@ from solstrale_amd import (CameraConfig, PathTracingShader, RenderConfig, Rotati
                            Translation, scenes)
 
 
-def random_scene(seed, width=40, height=32, spp=4, max_depth=12):
+def random_scene(seed, width=40, height=32, spp=4, max_depth=12, far=1.0):
+    """far > 1: the same scene seen through a long lens from `far` times the distance (what BASELINE config 2 does to its Cornell box from
+    800 units away: the hit parameters are large, the digits fp32 has left for them few)."""
     rng = np.random.default_rng(seed)
     b = SceneBuilder()
     u = lambda lo, hi: float(rng.uniform(lo, hi))
@@ -78,7 +80,11 @@ def random_scene(seed, width=40, height=32, spp=4, max_depth=12):
             world.append(b.Triangle(tuple(c), tuple(c + v3(-2., 2.)), tuple(c + v3(-2., 2.)), lm))
     order = rng.permutation(len(world))
     world = [world[i] for i in order]
-    cam = CameraConfig(u(25., 70.), 0. if rng.random() < 0.6 else u(0.02, 0.3), v3(-6., 6.)[:2] + (u(5., 9.),), v3(-1., 1.), (0., 1., 0.))
+    fov, aperture, look_from, look_at = u(25., 70.), 0. if rng.random() < 0.6 else u(0.02, 0.3), v3(-6., 6.)[:2] + (u(5., 9.),), v3(-1., 1.)
+    if far != 1.0:
+        look_from = tuple(np.asarray(look_at) + (np.asarray(look_from) - np.asarray(look_at)) * far)
+        fov = float(np.degrees(2. * np.arctan(np.tan(np.radians(fov) / 2.) / far)))
+    cam = CameraConfig(fov, aperture, look_from, look_at, (0., 1., 0.))
     rc = RenderConfig(width, height, spp, PathTracingShader(max_depth))
     return b.finish(b.Bvh(world), cam, v3(0., 0.6), rc)
 

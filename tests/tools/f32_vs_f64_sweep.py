@@ -2,7 +2,7 @@
 the double one - the reference's arithmetic - over seeded random scenes: relative difference of the frame means. Paths that round apart
 give differences of either sign around 1e-4 for single scenes and no mean; a RULE that loses or invents energy shows as a signed mean
 or as an outlier (round 4 found two that way: needle-shaped lights, and the needle rule inside a light's pdf_value).
-Usage: python f32_vs_f64_sweep.py [general|needle] [first_seed] [count] [spp]"""
+Usage: python f32_vs_f64_sweep.py [general|needle|far] [first_seed] [count] [spp]   (far: the general scenes from 100 times the distance)"""
 import _paths  # noqa: F401
 import sys
 
@@ -18,6 +18,8 @@ if __name__ == "__main__":
     count = int(sys.argv[3]) if len(sys.argv) > 3 else 400
     spp = int(sys.argv[4]) if len(sys.argv) > 4 else 64
     gen = random_scenes.needle_scene if kind == "needle" else random_scenes.random_scene
+    if kind == "far":
+        gen = lambda seed, spp: random_scenes.random_scene(seed, spp=spp, far=100.0)  # noqa: E731
     rows = []
     for seed in range(first, first + count):
         sc = gen(seed, spp=spp)
