@@ -420,9 +420,30 @@ template <typename R> struct Tracer {
     R a = r.direction.length_squared();
     R half_b = oc.dot(r.direction);
     R c = oc.length_squared() - S.radius * S.radius;
-    R disc = half_b * half_b - a * c;
-    if (disc < (R)0) return false;
-    R sqrt_d = std::sqrt(disc);
+    // fp32 contract (sixth rule): in single precision the reference's discriminant half_b^2 - a c is the difference of two
+    // numbers of the size a |oc|^2 - for an origin 800 units away it errs by 0.08, as much as r^2 - l^2 itself over the rim of a small sphere
+    // (hits missed, misses hit), and the roots lose the same digits. The float instantiation takes the discriminant from the distance l of
+    // the centre to the ray, a (r^2 - l^2) = half_b^2 - a c exactly, and the roots as q / a and c / q with q = -half_b -+ sqrt(..) of the sign
+    // that does not cancel (Haines, Guenther, Akenine-Moeller, "Precision improvements for ray / sphere intersection", Ray Tracing Gems 2019,
+    // ch. 7). Same roots, same order, to the last digits fp32 has. f64: the reference's lines, below.
+    R root_first, root_second;
+    if (sizeof(R) == 4) {
+      const R k = half_b / a;
+      const V3<R> l = oc - r.direction * k;
+      const R disc1 = S.radius * S.radius - l.length_squared();
+      if (disc1 < (R)0) return false;
+      const R sq = std::sqrt(a * disc1);
+      const R q = half_b >= (R)0 ? -half_b - sq : -half_b + sq;
+      const R rq = q / a, rc = c / q;
+      root_first = half_b >= (R)0 ? rq : rc;
+      root_second = half_b >= (R)0 ? rc : rq;
+    } else {
+      R disc = half_b * half_b - a * c;
+      if (disc < (R)0) return false;
+      R sqrt_d = std::sqrt(disc);
+      root_first = (-half_b - sqrt_d) / a;
+      root_second = (-half_b + sqrt_d) / a;
+    }
     // fp32 contract: in the float instantiation a root also has to put its hit point inside the sphere's own
     // box (centre +- radius, widened by half the box pad); the fp32 quadratic loses 7 digits for distant origins and would
     // otherwise report points that lie outside every box bounding the sphere. In f64 (the reference) nothing is added.
@@ -435,9 +456,9 @@ template <typename R> struct Tracer {
       }
       return true;
     };
-    R root = (-half_b - sqrt_d) / a;
+    R root = root_first;
     if (!root_ok(root)) {
-      root = (-half_b + sqrt_d) / a;
+      root = root_second;
       if (!root_ok(root)) return false;
     }
     V3<R> hp = r.at(root);

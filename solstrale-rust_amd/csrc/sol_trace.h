@@ -185,12 +185,18 @@ DEV bool sphere_test(const DSphere& S, f3 o, f3 d, float tmin, float tmax, float
   float a = len2(d);
   float half_b = dot3(oc, d);
   float c = len2(oc) - S.radius * S.radius;
-  float disc = half_b * half_b - a * c;
-  if (disc < 0.0f) return false;
-  float sqrt_d = sol_sqrt(disc);
-  float root = (-half_b - sqrt_d) / a;
+  // fp32 contract, sixth rule (oracle.cpp hit_sphere): the discriminant from the distance of the centre to the ray, the roots as q / a and
+  // c / q - the reference's half_b^2 - a c loses the digits of a distant origin (C2 +3.5 % for it, every other workload unchanged)
+  const float k = half_b / a;
+  const f3 l = oc - d * k;  // from the centre to the ray's closest point
+  const float disc1 = S.radius * S.radius - len2(l);
+  if (disc1 < 0.0f) return false;
+  const float sq = sol_sqrt(a * disc1);
+  const float q = half_b >= 0.0f ? -half_b - sq : -half_b + sq;
+  const float rq = q / a, rc = c / q;
+  float root = half_b >= 0.0f ? rq : rc;
   if (!sphere_root_ok(S, o, d, root, tmin, tmax, slack)) {
-    root = (-half_b + sqrt_d) / a;
+    root = half_b >= 0.0f ? rc : rq;
     if (!sphere_root_ok(S, o, d, root, tmin, tmax, slack)) return false;
   }
   t = root;
