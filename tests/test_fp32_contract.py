@@ -123,3 +123,17 @@ def test_spheres_through_a_long_lens():
         rel.append((a.mean() - b.mean()) / b.mean())
     assert max(abs(r) for r in rel) < 2e-3, rel   # (was up to 0.106)
     assert abs(sum(rel) / len(rel)) < 3e-4, rel
+
+
+def test_float_follows_double_on_the_reference_scenes():
+    """The second gate on the reference's own material: the 22 scenes of its golden images (tests/ref_cases.py), float oracle against
+    double oracle, frame means within 1e-4 (measured: at most 8e-6)."""
+    from ref_cases import CASES
+    for name, factory, w, h, ref_spp, spp in CASES:
+        n = max(spp, 16)
+        sc = factory(n)
+        a, _ = orc.render(sc, 0, n, pu.SEED, real=orc.ORC_F32)
+        b, _ = orc.render(sc, 0, n, pu.SEED, real=orc.ORC_F64)
+        ok = np.isfinite(a) & np.isfinite(b)  # (the Simple shader's colours can be NaN on both sides alike)
+        assert (np.isfinite(a) == np.isfinite(b)).all(), name
+        assert abs(a[ok].mean() - b[ok].mean()) <= 1e-4 * abs(b[ok].mean()), (name, a[ok].mean(), b[ok].mean())
