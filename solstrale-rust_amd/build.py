@@ -2,6 +2,7 @@
 
   libsolstrale_hip.so   hand-written HIP for gfx950 + the C ABI of include/solstrale_hip.h   (hipcc)
   libsolstrale_host.so  C++ host mirror of the reference's Scene / ray_trace surface          (g++)
+  profiling             the reference's profiling binary on the device path, native (examples/) (g++)
 
 hipcc cross-compiles gfx950 code objects without a GPU. -ffp-contract=off keeps the device arithmetic the plain
 IEEE sequence the parity tests pin (DESIGN.md "fp32 arithmetic contract"). Translation units are compiled in
@@ -26,6 +27,7 @@ HIP_HDR = ["csrc/sol_types.h", "csrc/sol_math.h", "csrc/sol_trace.h", "csrc/sol_
            "csrc/sol_tree.h", "csrc/sol_build.h", "csrc/sol_scene.h", "../include/solstrale_hip.h"]
 HOST_SRC = ["host/solstrale_host.cpp", "host/solstrale_obj.cpp", "host/solstrale_host_c.cpp"]
 HOST_DEPS = HOST_SRC + ["host/solstrale.hpp", "../include/solstrale_hip.h", "../include/solstrale_host.h"]
+EXAMPLES = ["examples/profiling.cpp"]  # native programs over the C++ host mirror (the reference's src/bin/profiling.rs); no Python, no torch
 
 # -packed-fp32-ops (target feature OFF): hipcc otherwise pairs fp32 multiplies and adds into v_pk_mul_f32 / v_pk_add_f32 /
 # v_pk_fma_f32 wherever it finds two alike (cross products of the triangle test, shading vectors). On MI355X a packed instruction
@@ -84,6 +86,11 @@ def build(force=False, extra_hip_flags=(), out_dir=None, ab_kernels=False):
     if force or _stale(host_lib, HOST_DEPS + ["build.py"]) or os.path.getmtime(hip_lib) > os.path.getmtime(host_lib):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-pthread"] + HOST_SRC +
              ["-o", host_lib, "-L" + out_dir, "-lsolstrale_hip", "-Wl,-rpath,$ORIGIN"])
+    for src in EXAMPLES:
+        exe = os.path.join(out_dir, os.path.splitext(os.path.basename(src))[0])
+        if force or _stale(exe, [src, "host/solstrale.hpp", "build.py"]) or os.path.getmtime(host_lib) > os.path.getmtime(exe):
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", src, "-o", exe, "-L" + out_dir, "-lsolstrale_host", "-lsolstrale_hip",
+                  "-Wl,-rpath,$ORIGIN"])
     return hip_lib, host_lib
 
 

@@ -545,13 +545,20 @@ std::string ray_trace(const Scene& scene, const std::function<void(RenderProgres
   // Passes are batched on the device; one RenderProgress per sample index is still emitted (tests drain the
   // channel, tests/integration_tests.rs:316-321) and abort is polled between batches (renderer/mod.rs:237).
   uint32_t batch = rc.render_image_strategy.kind == RenderImageStrategy::EverySample ? 1u : 8u;
-  if (rc.render_image_strategy.kind == RenderImageStrategy::OnlyFinal) batch = 64u;
+  // OnlyFinal shows nothing before the end, so a batch only bounds how long an abort waits: it doubles (multiples of 16, where the
+  // sums do not depend on the split - DESIGN.md 3) while a batch takes less than ~50 ms, so that a small scene is not rendered
+  // in launches of a few milliseconds each (the reference's profiling workload: 64-sample batches reach 2/3 of one launch's rate).
+  const bool only_final = rc.render_image_strategy.kind == RenderImageStrategy::OnlyFinal;
+  if (only_final) batch = 64u;
+  const uint32_t batch_cap = std::max(16u, sol_max_samples_per_call(dev) / 16u * 16u);
   uint32_t done = 0;
   while (done < spp) {
     if (abort && abort()) return "";
-    uint32_t n = std::min(batch, spp - done);
+    uint32_t n = std::min(std::min(batch, batch_cap), spp - done);
+    const double t_batch = secs(clk::now());
     if (sol_render(dev, done, n, rc.seed) != SOL_OK) return sol_last_error();
     if (sol_sync(dev) != SOL_OK) return sol_last_error();
+    if (only_final && secs(clk::now()) - t_batch < 0.05 && batch < batch_cap) batch *= 2u;
     for (uint32_t s = done + 1; s <= done + n; ++s) {
       double now = secs(clk::now());
       RenderProgress p;
