@@ -804,6 +804,19 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
         if (!cands.empty()) { rc = SOL_OK; continue; }  // (a later candidate failed: the earlier ones stand)
         break;
       }
+      // Small scenes: the radii often give the SAME tree (the layout is a function of the tree alone, so equal trees are equal
+      // bytes) - a duplicate is not uploaded and probed a second time (the reference's test scene: three times 33 identical nodes).
+      bool duplicate = false;
+      for (const TreeCand& p : cands) {
+        const WideLayout &a = p.lay, &b = c.lay;
+        if (p.emin != c.emin || a.nodes.size() != b.nodes.size() || a.leaf_refs != b.leaf_refs) continue;
+        if (std::memcmp(a.nodes.data(), b.nodes.data(), a.nodes.size() * sizeof(DWide)) != 0) continue;
+        if (a.old_of_new[0] == b.old_of_new[0] && a.old_of_new[1] == b.old_of_new[1] && a.old_of_new[2] == b.old_of_new[2]) { duplicate = true; break; }
+      }
+      if (duplicate) {
+        if (ovr.verbose) std::fprintf(stderr, "[solstrale] device tree (radius %d): the same tree as an earlier candidate, dropped\n", radius);
+        continue;
+      }
       cands.push_back(std::move(c));
       dev_info.push_back(si);
     }
