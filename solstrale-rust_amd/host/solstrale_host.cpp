@@ -544,11 +544,14 @@ std::string ray_trace(const Scene& scene, const std::function<void(RenderProgres
 
   // Passes are batched on the device; one RenderProgress per sample index is still emitted (tests drain the
   // channel, tests/integration_tests.rs:316-321) and abort is polled between batches (renderer/mod.rs:237).
-  uint32_t batch = rc.render_image_strategy.kind == RenderImageStrategy::EverySample ? 1u : 8u;
+  uint32_t batch = rc.render_image_strategy.kind == RenderImageStrategy::EverySample ? 1u : 16u;
   // OnlyFinal shows nothing before the end, so a batch only bounds how long an abort waits: it doubles (multiples of 16, where the
   // sums do not depend on the split - DESIGN.md 3) while a batch takes less than ~50 ms, so that a small scene is not rendered
   // in launches of a few milliseconds each (the reference's profiling workload: 64-sample batches reach 2/3 of one launch's rate).
+  // Interval: the same, with a batch kept below half the interval so that images still come when they are due.
   const bool only_final = rc.render_image_strategy.kind == RenderImageStrategy::OnlyFinal;
+  const bool interval = rc.render_image_strategy.kind == RenderImageStrategy::Interval;
+  const double grow_below = only_final ? 0.05 : interval ? std::min(0.05, 0.5 * rc.render_image_strategy.interval_seconds) : 0.0;
   if (only_final) batch = 64u;
   const uint32_t batch_cap = std::max(16u, sol_max_samples_per_call(dev) / 16u * 16u);
   uint32_t done = 0;
@@ -558,7 +561,7 @@ std::string ray_trace(const Scene& scene, const std::function<void(RenderProgres
     const double t_batch = secs(clk::now());
     if (sol_render(dev, done, n, rc.seed) != SOL_OK) return sol_last_error();
     if (sol_sync(dev) != SOL_OK) return sol_last_error();
-    if (only_final && secs(clk::now()) - t_batch < 0.05 && batch < batch_cap) batch *= 2u;
+    if (secs(clk::now()) - t_batch < grow_below && batch < batch_cap) batch *= 2u;
     for (uint32_t s = done + 1; s <= done + n; ++s) {
       double now = secs(clk::now());
       RenderProgress p;

@@ -691,6 +691,22 @@ def test_ray_trace_every_sample_and_abort():
     assert len(events) < 6  # aborted silently, Ok(()) like the reference (src/renderer/mod.rs:237-239)
 
 
+def test_ray_trace_interval_strategy_and_growing_batches():
+    """RenderImageStrategy::Interval (renderer/mod.rs:88-118): images now and then, always one with the last sample; the pass loop
+    hands the device batches that grow (multiples of 16: the sums do not depend on the split), so the final picture is OnlyFinal's."""
+    sc = scenes.cornell_box(RenderConfig(96, 64, 208))
+    events, final_only = sc.ray_trace()
+    assert len(events) == 208 and [e[3] for e in events].count(True) == 1
+    events, image = sc.ray_trace(strategy="interval", interval_seconds=0.0)
+    assert len(events) == 208 and events[-1][3] and [e[3] for e in events].count(True) >= 2
+    assert (image == final_only).all()
+    events, image = sc.ray_trace(strategy="interval", interval_seconds=3600.0)
+    assert len(events) == 208 and [e[3] for e in events].count(True) >= 1 and events[-1][3]
+    assert (image == final_only).all()
+    sums = gpu_render(sc, 208)
+    assert (image == im.sums_to_rgb8(sums, 208)).all()
+
+
 # ---- full BASELINE sizes: size-independent properties ------------------------------------------------------------------
 def test_full_size_c2_properties():
     """configs[1] at its full size (1920x1080, 256 spp, 10 000 spheres): additivity over sample ranges, partition
