@@ -27,6 +27,17 @@ def test_hip_library_exports_every_declared_symbol():
     assert sorted(_abi.HIP_SYMBOLS) == names
 
 
+def test_integration_guide_names_every_entry_point():
+    """INTEGRATION.md shows the reference-side binding: every entry point of the device header is declared in its `extern "C"` block
+    or named among the diagnostics a binding may leave out - a new entry point must not go undocumented."""
+    guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _declared("solstrale_hip.h", "sol_") if not re.search(r"\b" + n + r"\b", guide)]
+    assert not missing, f"INTEGRATION.md does not mention {missing}"
+    bound = set(re.findall(r"pub fn (sol_[a-z0-9_]+)", guide))
+    core = {"sol_scene_create", "sol_scene_destroy", "sol_render", "sol_read", "sol_clear", "sol_sync", "sol_comm_init", "sol_gather", "sol_last_error"}
+    assert core <= bound, f"the Rust extern block lacks {sorted(core - bound)}"
+
+
 def test_host_library_exports_every_declared_symbol():
     lib = _abi.load_host()
     names = [n for n in _declared("solstrale_host.h", "solh_") if not n.endswith("_fn")]
