@@ -128,6 +128,11 @@ def build_sanitized():
     if _stale(host_lib, HOST_DEPS + ["build.py"]) or os.path.getmtime(hip_lib) > os.path.getmtime(host_lib):
         _run([clang, "-std=c++17", "-fPIC", "-shared", "-shared-libsan", "-Wall", "-Wextra", "-pthread"] + SAN_FLAGS + HOST_SRC +
              ["-o", host_lib, "-L" + BUILD_SAN, "-lsolstrale_hip", "-Wl,-rpath,$ORIGIN"])
+    for src in EXAMPLES:
+        exe = os.path.join(BUILD_SAN, os.path.splitext(os.path.basename(src))[0])
+        if _stale(exe, [src, "host/solstrale.hpp", "build.py"]) or os.path.getmtime(host_lib) > os.path.getmtime(exe):
+            _run([clang, "-std=c++17", "-shared-libsan", "-Wall", "-Wextra", "-pthread"] + SAN_FLAGS + [src, "-o", exe, "-L" + BUILD_SAN, "-lsolstrale_host",
+                  "-lsolstrale_hip", "-Wl,-rpath,$ORIGIN"])
     oracle_lib = os.path.join(BUILD_SAN, "liboracle.so")
     odir = os.path.join(os.path.dirname(HERE), "oracle")
     if not os.path.exists(oracle_lib) or any(os.path.getmtime(os.path.join(odir, f)) > os.path.getmtime(oracle_lib) for f in ("oracle.cpp", "oracle.h")):
