@@ -470,7 +470,12 @@ typedef struct SolTreeCheck {
   uint32_t split_uncovered;    /* sample points of split triangles that no reference box of their triangle holds (must be 0) */
   uint32_t reserved;
 } SolTreeCheck;
+/* SolTreeCheck carries no size field and grew after its first release (the three split counters and `reserved`): sol_world_tree_check
+ * writes the FIRST layout only - the fields through leaf_area, SOL_TREE_CHECK_V1_BYTES - so a binding compiled against that header is never
+ * overrun; sol_world_tree_check_ex takes the caller's sizeof(SolTreeCheck) and fills every field that fits (the rest of `out` is zeroed). */
+#define SOL_TREE_CHECK_V1_BYTES 48
 int sol_world_tree_check(const SolSceneDesc* desc, int use_sah, SolTreeCheck* out);
+int sol_world_tree_check_ex(const SolSceneDesc* desc, int use_sah, void* out, size_t out_size);
 /* Diagnostic, host only: the background blocks (SolSceneInfo::background_blocks) found with the host-built tree `use_sah` (>= 0) names:
  * flags[b] = 1 for block b (row-major, (width + 7) / 8 blocks per row), *n_found their number. flags may be NULL. */
 int sol_background_blocks(const SolSceneDesc* desc, int use_sah, uint8_t* flags, size_t n_flags, uint32_t* n_found);

@@ -451,7 +451,7 @@ template <typename R> struct Tracer {
       if (!contains(tmin, tmax, root)) return false;
       if (sizeof(R) == 4) {
         const V3<R> p = r.at(root);
-        const R lim = S.radius + sphere_slack;
+        const R lim = std::fabs(S.radius) + sphere_slack;  // (|r|: the reference knows a radius only through r^2 and its min/max box - a negative one is the hollow-glass idiom)
         return std::fabs(p.x - S.center.x) <= lim && std::fabs(p.y - S.center.y) <= lim && std::fabs(p.z - S.center.z) <= lim;
       }
       return true;
@@ -478,7 +478,7 @@ template <typename R> struct Tracer {
     // t > 0.001: one more bounce, darker (Cornell box + 10 000 spheres: 7 % more rays, the frame 8 % darker than f64). The direction
     // centre -> point is good to an ulp whatever t is; the point at distance r along it is what f64 computes to 13 digits. Normal, uv and
     // tangents are taken from the point as computed, as before. f64: nothing changes.
-    if (sizeof(R) == 4) hp = S.center + n * (S.radius / n.length());
+    if (sizeof(R) == 4) hp = S.center + n * (std::fabs(S.radius) / n.length());  // (|r|: a negative radius must not send the point to the antipode)
     out = {root, hp, {tangent, bi_tangent, normal}, uv, front, S.mat};
     return true;
   }

@@ -131,6 +131,7 @@ int sol_rebuild_order(SolScene* s) {
 
 int sol_set_partition(SolScene* s, int rank, int world) {
   if (world < 1 || rank < 0 || rank >= world) return sol_fail(SOL_EINVAL, "bad partition %d/%d", rank, world);
+  const int rank_before = s->rank, world_before = s->world;
   s->rank = rank; s->world = world;
   const uint32_t nb = s->blocks_x * s->blocks_y;
   s->n_local_blocks = (nb + (uint32_t)world - 1u - (uint32_t)rank) / (uint32_t)world;  // blocks b with b % world == rank
@@ -182,7 +183,9 @@ int sol_set_partition(SolScene* s, int rank, int world) {
   size_t floats = (size_t)max_blocks * 64u * 3u;
   // a different block -> slot mapping: sums already in the accumulators (and the auxiliary planes) lie in the old layout - cleared,
   // so that a later sol_read cannot mix the two (the caller re-renders; a caller-bound accumulator was refused above)
-  if (had_sums && crc_before != s->partition_crc && floats == s->acc_floats && s->acc == s->acc_own) {
+  // (the checksum is rank-independent - every rank of a job reports the same one -, so a change of rank alone is compared too)
+  const bool layout_changed = crc_before != s->partition_crc || rank_before != rank || world_before != world;
+  if (had_sums && layout_changed && floats == s->acc_floats && s->acc == s->acc_own) {
     HIP_TRY(hipMemsetAsync(s->acc_own, 0, s->acc_floats * sizeof(float), s->stream));
     for (int k = 0; k < 2; ++k)
       if (s->aux[k] && s->aux_floats == s->acc_floats) HIP_TRY(hipMemsetAsync(s->aux[k], 0, s->aux_floats * sizeof(float), s->stream));

@@ -277,9 +277,7 @@ static SolSplitOptions split_options(const SolDevOverrides& ovr, const SolCreate
   return sp;
 }
 
-extern "C" {
-
-int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) {
+static int world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) {
   if (!d || !out) return sol_fail(SOL_EINVAL, "null argument");
   std::memset(out, 0, sizeof *out);
   const SolDevOverrides ovr = sol_dev_overrides();
@@ -453,6 +451,21 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
   return SOL_OK;
 }
 
+extern "C" {
+
+// The struct has no size field of its own and grew in round 4 (the three split counters): the plain entry point keeps writing the FIRST
+// LAYOUT (through leaf_area, SOL_TREE_CHECK_V1_BYTES) so that a binding compiled against that header is not overrun; callers of this
+// header pass their struct's size to sol_world_tree_check_ex and get every field that fits.
+int sol_world_tree_check_ex(const SolSceneDesc* d, int use_sah, void* out, size_t out_size) {
+  if (!out || out_size < SOL_TREE_CHECK_V1_BYTES) return sol_fail(SOL_EINVAL, "sol_world_tree_check_ex: out is null or smaller than the first layout (%d bytes)", (int)SOL_TREE_CHECK_V1_BYTES);
+  SolTreeCheck full;
+  const int rc = world_tree_check(d, use_sah, &full);
+  std::memset(out, 0, out_size);
+  std::memcpy(out, &full, std::min(out_size, sizeof full));
+  return rc;
+}
+int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) { return sol_world_tree_check_ex(d, use_sah, out, SOL_TREE_CHECK_V1_BYTES); }
+
 // Diagnostic, host only: the background blocks sol_scene_create would find with the host-built tree `use_sah` names (as in
 // sol_world_tree_check; the proof does not depend on which tree carries it, the count may).
 int sol_background_blocks(const SolSceneDesc* d, int use_sah, uint8_t* flags, size_t n_flags, uint32_t* n_found) {
@@ -602,7 +615,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     const SolSphere& s = d->spheres[i];
     if (!mat_ok(s.material)) return sol_fail(SOL_EINVAL, "sphere %u: bad material", i);
     DSphere& o = spheres[i];
-    o.cx = (float)s.center[0]; o.cy = (float)s.center[1]; o.cz = (float)s.center[2]; o.radius = (float)s.radius;
+    o.cx = (float)s.center[0]; o.cy = (float)s.center[1]; o.cz = (float)s.center[2]; o.radius = std::fabs((float)s.radius);  // |r|: the reference uses r^2 and a min/max box only (sphere.rs:26-28,68), the fp32 rules of sol_trace.h / sol_shade.h use r itself
     o.dfs = s.dfs_index; o.mat = s.material; o.pad0 = o.pad1 = 0;
   }
 

@@ -191,6 +191,7 @@ def load_hip():
     _sig(lib, "sol_gaussian_blur_weights", C.c_int, [C.c_uint32, C.c_double, C.POINTER(C.c_double)])
     _sig(lib, "sol_stats", C.c_int, [P, C.POINTER(SolStats)])
     _sig(lib, "sol_world_tree_check", C.c_int, [C.c_void_p, C.c_int, C.POINTER(SolTreeCheck)])
+    _sig(lib, "sol_world_tree_check_ex", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t])
     _sig(lib, "sol_record_sizes", C.c_int, [C.POINTER(C.c_uint32)])
     _sig(lib, "sol_last_error", C.c_char_p, [])
     _sig(lib, "sol_debug_path", C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32])
@@ -218,7 +219,7 @@ HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol
                "sol_accum_floats", "sol_accum_ptr", "sol_scene_bind_accum", "sol_scene_set_stream", "sol_clear",
                "sol_render", "sol_render_counted", "sol_sync", "sol_read", "sol_unpermute", "sol_tonemap_rgb8",
                "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms",
-               "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check", "sol_render_aux", "sol_clear_aux", "sol_read_aux",
+               "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check", "sol_world_tree_check_ex", "sol_render_aux", "sol_clear_aux", "sol_read_aux",
                "sol_scene_create_ex", "sol_scene_build_times", "sol_scene_set_option", "sol_scene_info", "sol_path_stats", "sol_comm_unique_id", "sol_comm_init",
                "sol_comm_destroy", "sol_gather", "sol_comm_self_check", "sol_read_image", "sol_max_samples_per_call", "sol_background_blocks"]
 

@@ -49,7 +49,7 @@ def world_tree_check(scene, use_sah):
     """Host-only structural check of the 8-wide tree sol_scene_create would build for `scene` (no device needed)."""
     lib = _abi.load_hip()
     out = _abi.SolTreeCheck()
-    rc = lib.sol_world_tree_check(scene.desc_ptr, int(use_sah), C.byref(out))
+    rc = lib.sol_world_tree_check_ex(scene.desc_ptr, int(use_sah), C.byref(out), C.sizeof(out))  # (the size-prefixed form: every field)
     if rc != 0:
         raise DeviceError(rc, lib.sol_last_error().decode())
     return out.as_dict()

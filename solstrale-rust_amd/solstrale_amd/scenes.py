@@ -383,6 +383,8 @@ def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1
     elif camera == "default":
         cam = CameraConfig(vertical_fov_degrees=55., aperture_size=0., look_from=(-13.0, 2.2, 0.6), look_at=(6.0, 4.5, -0.4),
                            up=(0, 1, 0))
+    elif camera == "far":  # a long lens 190 units above the hall, looking down through the roof opening past the light: floor, galleries, drapes
+        cam = CameraConfig(vertical_fov_degrees=7.5, aperture_size=0., look_from=(47.0, 181.0, 34.0), look_at=(0.0, 3.0, 0.0), up=(0, 1, 0))
     else:
         raise ValueError(f"unknown camera preset {camera!r}")
     return b.finish(world, cam, (0.35, 0.5, 0.75), rc)
@@ -519,6 +521,8 @@ def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES, environment=Fa
         cam = CameraConfig(vertical_fov_degrees=40., aperture_size=0., look_from=(1.6, 7.2, 3.4), look_at=(0.0, 3.1, 0.0), up=(0, 1, 0))
     elif camera == "default":
         cam = CameraConfig(vertical_fov_degrees=38., aperture_size=0., look_from=(4.5, 3.6, 8.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
+    elif camera == "far":  # the default view from ten times the distance through a lens ten times as long (the regime in which fp32 loses a distant origin's digits)
+        cam = CameraConfig(vertical_fov_degrees=3.94, aperture_size=0., look_from=(43.2, 12.6, 80.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
     else:
         raise ValueError(f"unknown camera preset {camera!r}")
     if environment:  # EXTENSION (not in the reference): the "HDRI env light" of BASELINE.json's config 5, as a procedural HDR sky

@@ -115,3 +115,19 @@ def test_scene_extent_is_bounded_before_the_device():
     with pytest.raises(DeviceError) as e:
         DeviceScene(sc)
     assert e.value.code == _abi.SOL_EINVAL and "2^38" in e.value.msg
+
+
+def test_tree_check_keeps_its_first_layout_for_old_bindings():
+    """SolTreeCheck has no size field and grew in round 4: the plain entry point writes the 48-byte first layout only (a binding compiled
+    against that header is not overrun), sol_world_tree_check_ex fills what the caller's size holds and refuses less than the first layout."""
+    from solstrale_amd import RenderConfig, scenes
+    lib = _abi.load_hip()
+    assert C.sizeof(_abi.SolTreeCheck) == 64 and _abi.SolTreeCheck.n_extra_references.offset == 48
+    sc = scenes.cornell_box(RenderConfig(32, 32, 1))
+    buf = (C.c_uint8 * 80)(*([0xAB] * 80))
+    assert lib.sol_world_tree_check(sc.desc_ptr, 0, C.cast(buf, C.POINTER(_abi.SolTreeCheck))) == 0
+    assert all(b == 0xAB for b in buf[48:]) and any(b != 0xAB for b in buf[:48])
+    full = _abi.SolTreeCheck()
+    assert lib.sol_world_tree_check_ex(sc.desc_ptr, 0, C.byref(full), C.sizeof(full)) == 0
+    assert bytes(buf[:48]) == bytes(full)[:48] and full.n_wide >= 1 and full.leaf_mismatches == 0
+    assert lib.sol_world_tree_check_ex(sc.desc_ptr, 0, C.byref(full), 40) == _abi.SOL_EINVAL

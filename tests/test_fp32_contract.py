@@ -109,6 +109,36 @@ def test_sphere_hit_points_lie_on_the_sphere():
     assert abs(a.mean() - b.mean()) < 1.5e-2 * b.mean(), (a.mean(), b.mean())  # (was -8.3 %; two f64 sample sets of this size differ by ~0.5 %)
 
 
+def hollow_glass_scene(render_config):
+    """The hollow-glass idiom: a glass sphere with a second sphere of NEGATIVE radius inside it (the reference knows a radius only through
+    r^2 and the min/max box of Sphere::new, sphere.rs:26-28,68: the negative one behaves like its positive twin), a glass sphere of
+    negative radius on its own, and a sphere LIGHT of negative radius - over a floor."""
+    b = SceneBuilder()
+    glass = b.Dielectric(b.SolidColor(1., 1., 1.), None, 1.5)
+    world = [b.Quad((-8., 0., -8.), (16., 0., 0.), (0., 0., 16.), b.Lambertian(b.SolidColor(.6, .6, .55))),
+             b.Sphere((-1.6, 1.0, 0.), 1.0, glass), b.Sphere((-1.6, 1.0, 0.), -0.85, glass),
+             b.Sphere((1.4, 0.8, 0.5), -0.8, glass),
+             b.Sphere((0., 5., -1.), -0.7, b.DiffuseLight(14., 13., 12.)),
+             b.Sphere((0.3, 0.5, 2.2), 0.5, b.Lambertian(b.SolidColor(.7, .3, .2)))]
+    cam = CameraConfig(35., 0., (0., 2.4, 9.), (0., 1., 0.), (0., 1., 0.))
+    return b.finish(b.Bvh(world), cam, (.25, .3, .4), render_config)
+
+
+def test_a_negative_radius_is_its_positive_twin():
+    """Round-4 advisor finding: the fifth rule put a sphere's hit point back at centre + n * (r / |n|) with the SIGNED radius - for the
+    hollow-glass idiom's negative radius the antipode, the next ray then started on the wrong side - and the second rule's own-box test
+    compared against r + slack < 0, which refuses every root. Both sides made the same mistake, so only f64 could see it. The fp32 rules
+    now use |r| (the device record stores it): float follows double, and the scene with the signs flipped renders the same float frame."""
+    spp = 48
+    sc = hollow_glass_scene(RenderConfig(120, 80, spp, PathTracingShader(12)))
+    a, sa = orc.render(sc, 0, spp, pu.SEED, real=orc.ORC_F32)
+    b, sb = orc.render(sc, 0, spp, pu.SEED, real=orc.ORC_F64)
+    assert b.mean() > 0.05 * spp and np.isfinite(a).all()
+    assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) < 3e-3 * sb["rays"] / sb["samples"], (sa, sb)
+    assert abs(a.mean() - b.mean()) < 3e-3 * b.mean(), (a.mean(), b.mean())  # (two f64 sample sets of this size differ by ~1e-2)
+    assert (np.abs(a - b).max(axis=-1) > 1e-3 * spp).mean() < 0.02
+
+
 def test_spheres_through_a_long_lens():
     """Sixth fp32-only rule: the sphere test takes its discriminant from the distance of the centre to the ray and its roots without
     cancellation. With the reference's formula in single precision the random scenes seen from 100 times the distance (objects of size 1

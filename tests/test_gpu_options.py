@@ -98,6 +98,24 @@ def test_bad_creation_options_are_rejected():
     assert e.value.code == _abi.SOL_EINVAL
 
 
+def test_a_change_of_rank_clears_the_sums_of_the_old_layout():
+    """sol_scene_set_partition: sums already in the accumulators lie in the OLD block -> slot layout; with the modulo partition the
+    partition checksum depends on (world, blocks) only, so set_partition(3, 8) -> render -> set_partition(5, 8) -> render -> read used to
+    hand back rank 3's sums in rank 5's pixels (round-4 advisor finding). The guard now compares rank and world as well."""
+    sc = scenes.cornell_box(RenderConfig(96, 64, 8))
+    with DeviceScene(sc) as ds:
+        ds.set_partition(5, 8)
+        ds.render(0, 8, pu.SEED)
+        want = ds.read()
+        ds.set_partition(3, 8)
+        ds.clear()
+        ds.render(0, 8, pu.SEED)
+        ds.set_partition(5, 8)   # no clear by the caller
+        ds.render(0, 8, pu.SEED)
+        got = ds.read()
+    assert want.any() and (got == want).all()
+
+
 def test_rebinding_rules_of_a_caller_bound_accumulator():
     """sol_scene_set_partition refuses to drop a caller-bound accumulator silently (it would keep gathering from a buffer that
     is no longer written)."""

@@ -307,6 +307,13 @@ def test_sphere_phantom_hits_are_layout_independent():
             assert np.abs(gc - oc).max() <= 1e-5 * max(1e-3, np.abs(oc).max())
 
 
+def test_negative_radius_spheres():
+    """The hollow-glass idiom (a sphere of negative radius: sphere.rs uses r^2 and a min/max box only) through the device: the fp32 rules
+    that use the radius itself use |r| (tests/test_fp32_contract.py::test_a_negative_radius_is_its_positive_twin ties float to f64)."""
+    from test_fp32_contract import hollow_glass_scene
+    assert_parity(hollow_glass_scene(RenderConfig(240, 160, 16, PathTracingShader(12))), 16)
+
+
 # ---- the reference's own scenes: every material, primitive and shader -------------------------------------------------
 def test_reference_test_scene_all_features():
     """tests/scenes.rs:17-122: image texture, glass, rotated boxes, ConstantMedium, nested BVH, sphere + quad + triangle
