@@ -326,13 +326,14 @@ template <typename R> struct Cand {
   uint32_t ref = 0;  // the primitive that was hit (diagnostics)
 };
 
-struct Counters { uint64_t rays = 0, node_visits = 0, sphere_tests = 0, quad_tests = 0, tri_tests = 0, shades = 0, texels = 0, samples = 0; };
+struct Counters { uint64_t rays = 0, node_visits = 0, sphere_tests = 0, quad_tests = 0, tri_tests = 0, shades = 0, texels = 0, samples = 0, live_rays = 0; };
 
 template <typename R> struct Tracer {
   const Scene<R>& sc;
   Counters cnt;
   Rng rng;
   uint32_t cur_depth = 0;  // depth of the ray being searched (medium sub-stream key)
+  bool live = true;        // no level of the current path has multiplied by zero yet (OrcStats::live_rays)
   std::vector<float>* trace = nullptr;  // diagnostics: 12 floats per ray (orc_debug_path)
   R sphere_slack = 0;                   // half the fp32 box pad (float instantiation only)
   explicit Tracer(const Scene<R>& s) : sc(s) { sphere_slack = s.box_pad * (R)0.5; }
@@ -721,6 +722,7 @@ template <typename R> struct Tracer {
 
   AttCol ray_color(const Ray<R>& ray, uint32_t depth, R acc_len) {
     cnt.rays++;
+    if (live) cnt.live_rays++;  // (OrcStats::live_rays: the rays the device traces too)
     cur_depth = depth;
     Cand<R> c;
     const bool any_hit = hit_ref(sc.root, ray, (R)RAY_MIN, std::numeric_limits<R>::infinity(), c);
@@ -749,6 +751,10 @@ template <typename R> struct Tracer {
     R total = rec.t + acc_len;
     Scatter s = scatter(rec.mat, ray, rec);
     if (s.type == 2) return {s.color, s.has_af, s.af, total};
+    if (s.type == 0) {  // a ScatterPdf level whose factor has no positive component returns 0 whatever its child returns: the device stops here
+      const V3<R> a = s.color * s.probability;
+      if (!(a.x > (R)0 || a.y > (R)0 || a.z > (R)0)) live = false;
+    }
     AttCol child = ray_color(s.ray, depth + 1, total);
     if (s.type == 1) return {s.color * child.color, child.has_af, child.af, child.len};
     V3<R> sc_col = s.color * s.probability * child.color;
@@ -760,6 +766,7 @@ template <typename R> struct Tracer {
     uint32_t row = (sc.height - 1) - y_ref;
     rng.init(seed, row * sc.width + x, sample);
     cnt.samples++;
+    live = true;
     R u = ((R)x + rnd()) / (R)(sc.width - 1);
     R v = ((R)y_ref + rnd()) / (R)(sc.height - 1);
     float uf = (float)u, vf = (float)v;
@@ -812,7 +819,7 @@ int render_impl(const SolSceneDesc* d, uint32_t x0, uint32_t y0, uint32_t x1, ui
     for (auto& c : counters) {
       stats->samples += c.samples; stats->rays += c.rays; stats->node_visits += c.node_visits;
       stats->sphere_tests += c.sphere_tests; stats->quad_tests += c.quad_tests; stats->triangle_tests += c.tri_tests;
-      stats->shades += c.shades; stats->texel_fetches += c.texels;
+      stats->shades += c.shades; stats->texel_fetches += c.texels; stats->live_rays += c.live_rays;
     }
     stats->threads = (uint32_t)threads;
   }

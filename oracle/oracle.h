@@ -16,6 +16,10 @@ extern "C" {
 typedef struct OrcStats {
   uint64_t samples, rays, node_visits, sphere_tests, quad_tests, triangle_tests, shades, texel_fetches;
   uint32_t threads, _pad;
+  /* rays of `rays` that the DEVICE traces as well: it ends a path at a ScatterPdf level whose factor colour * probability has no positive
+   * component (that level returns exactly 0 whatever lies beyond it, shader.rs:95-125; csrc/sol_path.h shade_vertex), the reference
+   * traces on. rays - live_rays = searches whose result the reference multiplies by zero. */
+  uint64_t live_rays;
 } OrcStats;
 
 /* Renders samples [first, first+n) of the pixels in [x0,x1) x [y0,y1) (output coordinates, row 0 = top) and ADDS

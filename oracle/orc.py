@@ -22,7 +22,7 @@ ORC_F64, ORC_F32 = 0, 1
 class OrcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "node_visits", "sphere_tests", "quad_tests",
                                           "triangle_tests", "shades", "texel_fetches")] + \
-               [("threads", C.c_uint32), ("_pad", C.c_uint32)]
+               [("threads", C.c_uint32), ("_pad", C.c_uint32), ("live_rays", C.c_uint64)]  # live_rays: the rays the device traces too (oracle.h)
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "_pad"}

@@ -16,7 +16,9 @@ difference of either sign, a RULE that loses or invents energy (or rays) a signe
   apart      fraction of pixels whose fp32 and f64 values differ by more than 1e-4 + 1e-3 |f64| in some channel (paths that rounded apart)
   z          sum of the pixel differences / sqrt(sum of their squares): the differences' own t statistic; independent zero-mean
              differences give |z| ~ 1, a one-signed offset over n pixels sqrt(n)
-  rays       rays per sample of the fp32 side and of f64 on the crop as a WINDOW frame (parity_util.WindowScene), and their ratio - 1
+  rays       rays per sample of the fp32 side and of f64 on the crop as a WINDOW frame (parity_util.WindowScene), and their ratio - 1. Rays = the
+             searches the DEVICE runs (SolStats::rays): it ends a path at a ScatterPdf level whose factor is zero, where the reference traces on
+             and multiplies by zero; the oracle counts those apart (OrcStats::live_rays = the device's definition)
 """
 import numpy as np
 
@@ -59,7 +61,7 @@ def float_oracle_frame(scene, spp, rect):
 
 def float_oracle_window(win, spp):
     _, st = orc.render(win, 0, spp, pu.SEED, real=orc.ORC_F32)
-    return st["rays"], st["samples"]
+    return st["live_rays"], st["samples"]
 
 
 def measure(scene, rect, spp, fp32_frame, fp32_window_rays):
@@ -81,7 +83,7 @@ def measure(scene, rect, spp, fp32_frame, fp32_window_rays):
     win = pu.WindowScene(scene, rect)
     rays32, samples32 = fp32_window_rays(win, spp)
     _, st = orc.render(win, 0, spp, pu.SEED, real=orc.ORC_F64)
-    r32, r64 = rays32 / samples32, st["rays"] / st["samples"]
+    r32, r64 = rays32 / samples32, st["live_rays"] / st["samples"]
     return {"mean_f64": float(mean), "rel": float((g.mean() - mean) / mean), "noise": float(noise), "two_sets": float((b.mean() - mean) / mean),
             "apart": float(apart.mean()), "z": float(d.sum() / ss) if ss > 0 else 0.0,
             "rays_fp32": float(r32), "rays_f64": float(r64), "rays_rel": float(r32 / r64 - 1.0)}

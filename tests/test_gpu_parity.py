@@ -558,6 +558,11 @@ def test_counters_match_definitions():
     assert (counted == plain).all()  # instrumentation does not change results
     assert st["samples"] == 64 * 64 * 4
     assert st["rays"] >= st["samples"] and st["node_visits"] > st["rays"] and st["quad_tests"] > 0
+    # SolStats::rays = the searches the device runs = the oracle's live_rays (it ends a path where a ScatterPdf level multiplies by zero;
+    # the reference - OrcStats::rays - traces on): equal to the ray when every path matches
+    _, ost = orc.render(sc, 0, 4, pu.SEED, real=orc.ORC_F32)
+    assert ost["samples"] == st["samples"] and ost["rays"] >= ost["live_rays"]
+    assert abs(st["rays"] - ost["live_rays"]) <= 1e-3 * ost["live_rays"], (st["rays"], ost["live_rays"], ost["rays"])
     # (18 quads: the collapse may hang the wide nodes in a chain - one inner child each - and then no sibling group is ever pushed)
     assert st["sphere_tests"] == 0 and st["triangle_tests"] == 0 and 0 <= st["max_stack"] <= 21  # two dwords per level of the 7-wide tree
 
