@@ -31,7 +31,8 @@ def test_single_gpu_line_has_the_contract_fields():
     assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
     assert d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["dtype"] == "f32"
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    # (`bound` names the contract's figure for what it is - algorithmic bytes against the HBM peak -, `binding` what limits the kernel)
+    assert rf["bound"] == "algorithmic_hbm" and rf["binding"] == "valu_issue" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     # traffic is either measured in this run (rocprofv3 --pmc passes) or null with the reason
     assert (rf["traffic"] is None and rf["traffic_source"].startswith("not measured")) or rf["traffic"] > 0
     if rf["traffic"]:
@@ -53,6 +54,19 @@ def test_rehearsal_without_a_launcher_goes_through_sol_gather(ranks, scaling, sp
     d = _line(r.stdout)
     assert d["n_gpus"] == ranks and d["scaling"] == scaling and d["config"]["spp_total"] == spp_total
     assert d["rehearsal_frame_check"] is True and d["rccl_ranks"] == ranks and "sol_gather" in d["config"]["sharding"]
+
+
+def test_both_figures_in_a_multi_rank_line():
+    """A scene with background blocks (the C3 atrium's sky) through two ranks: the N > 1 line carries the figure with every sample traced
+    as well, from as many steps as `value` (round-4 review: a scaling curve must not quote only the flattering figure)."""
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--workload", "c3", "--spp", "16", "--steps", "2", "--warmup", "1", "--rehearse", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    bb = d["background_blocks"]
+    assert d["n_gpus"] == 2 and bb["blocks"] > 0 and bb["value_with_every_sample_traced"] > 0 and bb["value_with_every_sample_traced_steps"] == 2
+    assert d["rehearsal_frame_check"] is True
 
 
 def test_a_supplied_obj_replaces_the_stand_in():
