@@ -46,7 +46,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 SEED = 0x5017A1E
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 N_SIMD = 256 * 4
-KERNEL = "sol_render_kernel<false"  # the uncounted product kernel (probes at scene creation run the counted variant)
+KERNEL = os.environ.get("SOL_BENCH_KERNEL", "sol_render_kernel<false")  # the uncounted product kernel (probes at scene creation run the counted variant); env: A/B runs of another kernel
 
 
 def algorithmic_bytes(st, sizes):

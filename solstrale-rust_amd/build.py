@@ -8,8 +8,8 @@ hipcc cross-compiles gfx950 code objects without a GPU. -ffp-contract=off keeps 
 IEEE sequence the parity tests pin (DESIGN.md "fp32 arithmetic contract"). Translation units are compiled in
 parallel to objects (only the stale ones) and linked; `build(out_dir=..., extra_hip_flags=...)` makes an A/B variant
 of the device library elsewhere (tests/tools/variants.py), selected at run time through SOLSTRALE_BUILD_DIR.
-`build_ab()` makes _build_ab/: the same library plus the two wavefront render-kernel variants (-DSOL_AB_KERNELS +
-csrc/sol_wavefront.hip), which the product library does not carry. Rejected experiments are not kept in the sources: their records
+`build_ab()` makes _build_ab/: the same library plus the measured-and-rejected render-kernel variants (-DSOL_AB_KERNELS +
+csrc/sol_wavefront.hip: the two wavefront kernels; csrc/sol_pool.hip: the pool kernel), which the product library does not carry. Rejected experiments are not kept in the sources: their records
 are profiles/*_ab.txt and the git history.
 """
 import os
@@ -59,7 +59,7 @@ def build(force=False, extra_hip_flags=(), out_dir=None, ab_kernels=False):
     host_lib = os.path.join(out_dir, "libsolstrale_host.so")
     flags_file = os.path.join(out_dir, "hip_flags.txt")
     flags = HIP_FLAGS + (["-DSOL_AB_KERNELS"] if ab_kernels else []) + list(extra_hip_flags)
-    sources = HIP_SRC + (["csrc/sol_wavefront.hip"] if ab_kernels else [])
+    sources = HIP_SRC + (["csrc/sol_wavefront.hip", "csrc/sol_pool.hip"] if ab_kernels else [])
     want = " ".join(flags + sources)
     have = open(flags_file).read() if os.path.exists(flags_file) else None
     if have != want:

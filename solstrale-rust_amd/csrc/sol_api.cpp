@@ -36,7 +36,7 @@ SolDevOverrides sol_dev_overrides() {
   auto num = [](const char* name, int unset) { const char* v = std::getenv(name); return v ? std::atoi(v) : unset; };
   if (const char* kv = std::getenv("SOL_KERNEL")) {
     if (kv[0] == 'v') kv++;
-    o.kernel_version = (kv[0] >= '1' && kv[0] <= '3') ? kv[0] - '0' : 0;
+    o.kernel_version = (kv[0] >= '1' && kv[0] <= '4') ? kv[0] - '0' : 0;
   }
   if (const char* v = std::getenv("SOL_BVH")) o.bvh = std::strcmp(v, "sah") == 0 ? "sah16" : v;
   if (const char* v = std::getenv("SOL_COLLAPSE")) o.greedy_collapse = std::strcmp(v, "greedy") == 0;
@@ -55,6 +55,7 @@ SolDevOverrides sol_dev_overrides() {
   o.switch_below = std::min(64, num("SOL_SWITCH", -1));
   o.max_bpc = num("SOL_MAX_BPC", -1);
   o.fine_tail = std::max(-2, num("SOL_FINE_TAIL", -2));
+  o.pool_swap_min = std::max(0, num("SOL_POOL_SWAP", 0));
   o.pool_slots = std::max(0, num("SOL_POOL_SLOTS", 0));
   o.wf_slots = std::max(0, num("SOL_WF_SLOTS", 0));
   o.wf_min_items = num("SOL_WF_MIN_ITEMS", -1);
@@ -277,9 +278,9 @@ int sol_scene_set_option(SolScene* s, int option, int64_t value) {
       s->max_bpc = (int)value;
       return SOL_OK;
     case SOL_OPT_KERNEL:
-      if (value < 0 || value > 3) return sol_fail(SOL_EINVAL, "SOL_OPT_KERNEL: 0..3");
+      if (value < 0 || value > 4) return sol_fail(SOL_EINVAL, "SOL_OPT_KERNEL: 0..4");
 #ifndef SOL_AB_KERNELS
-      if (value > 1) return sol_fail(SOL_EINVAL, "SOL_OPT_KERNEL %d: the wavefront variants exist only in -DSOL_AB_KERNELS builds of the library", (int)value);
+      if (value > 1) return sol_fail(SOL_EINVAL, "SOL_OPT_KERNEL %d: the wavefront and pool variants exist only in -DSOL_AB_KERNELS builds of the library", (int)value);
 #endif
       s->kernel_version = (int)value;
       return SOL_OK;

@@ -887,6 +887,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
       return e;
     }
     t.emin = c.emin; t.depth = c.depth; t.root = L.remap(root_ref); t.light0 = plights.empty() ? 0u : plights[0];
+    t.n_wide = (uint32_t)L.nodes.size(); t.packed_depth = L.depth + medium_depth + 2u;  // (depth_of: 2 * L.depth + medium_depth + 2 with two dwords per group)
     t.old_tri = L.old_of_new[0]; t.old_sphere = L.old_of_new[1]; t.old_quad = L.old_of_new[2];
     return SOL_OK;
   };
@@ -897,7 +898,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     DevScene& S = s->S;
     S.nodes = t.nodes; S.wides = t.wides; S.leaf_refs = t.leaf_refs; S.tris = t.tris; S.tri_shade = t.tri_shade; S.quads = t.quads; S.spheres = t.spheres;
     S.mediums = t.mediums; S.lights = t.lights; S.light0 = t.light0; S.wroot = 0; S.wide_emin = t.emin; S.root = t.root;
-    s->tree_depth = t.depth;
+    s->tree_depth = t.depth; s->n_wide = t.n_wide; s->packed_depth = t.packed_depth;
     t = DevTree{};
   };
   if ((rc = upload_tree(cands[0])) || (rc = sol_upload(mats, &s->mats)) || (rc = sol_upload(texs, &s->texs))) return rc;
@@ -934,6 +935,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   S.bgx = (float)d->background[0]; S.bgy = (float)d->background[1]; S.bgz = (float)d->background[2];
   S.cam = cast_camera(d->camera);
   s->kernel_version = ovr.kernel_version;
+  s->pool_swap_min = (uint32_t)ovr.pool_swap_min;
   s->order_mode = ovr.order_mode;
   // v1's search/shade switch (RenderParams::switch_below), measured on MI355X at 1080p x 128 spp (ms, C1 / C2 / C3 / test scene):
   // 0: 29.2 / 162.9 / 236.7 / 25.9, 8: 27.7 / 124.3 / 193.1 / 25.5, 16: 27.5 / 111.8 / 186.9 / 25.6, 24: 28.6 / 108.6 / 192.3 / 26.8.
@@ -971,7 +973,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
       DevTree& back = cands[current].dev;
       back.nodes = s->nodes; back.wides = s->wides; back.leaf_refs = s->leaf_refs; back.tris = s->tris; back.tri_shade = s->tri_shade;
       back.quads = s->quads; back.spheres = s->spheres; back.mediums = s->mediums; back.lights = s->lights;
-      back.emin = S.wide_emin; back.depth = s->tree_depth; back.root = S.root; back.light0 = S.light0;
+      back.emin = S.wide_emin; back.depth = s->tree_depth; back.root = S.root; back.light0 = S.light0; back.n_wide = s->n_wide; back.packed_depth = s->packed_depth;
       back.old_tri = std::move(s->old_index[0]); back.old_sphere = std::move(s->old_index[1]); back.old_quad = std::move(s->old_index[2]);
       adopt_tree(cands[k].dev);
       current = k;

@@ -29,6 +29,26 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   P.n_local_blocks = s->n_local_blocks; P.blocks_x = s->blocks_x;
   P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
   int version = s->kernel_version ? s->kernel_version : 1;
+  // version 4, the pool kernel (sol_pool.hip): plain renders of the path-tracing... any shader; counted renders (probes, statistics) and trees
+  // of 2^17 wide nodes or more (its one-dword node groups carry a 17-bit base) stay with the one-path-per-lane kernel
+  if (version == 4 && ((count && !std::getenv("SOL_POOL_COUNT")) || s->n_wide >= SOL_PACK_MAX_NODES)) version = 1;  // (SOL_POOL_COUNT: phase statistics of the pool kernel)
+  // one launch of the pool kernel stages ONE COLOUR PER SAMPLE: a long sample range goes through several launches (chunk-aligned, so the sums
+  // do not depend on the split), each within the staging budget
+  if (version == 4) {
+    const uint64_t pairs_per_chunk = (uint64_t)s->n_local_blocks;
+    const uint64_t max_chunks = std::max<uint64_t>(1, std::min<uint64_t>((6ull << 30) / std::max<uint64_t>(1, pairs_per_chunk * 64u * SOL_CHUNK * 12u),
+                                                                         (uint64_t)SOL_MAX_ITEMS / std::max<uint64_t>(1, pairs_per_chunk * 64u * SOL_CHUNK)));
+    if ((uint64_t)(n + SOL_CHUNK - 1) / SOL_CHUNK > max_chunks) {
+      uint32_t f = first, left = n;
+      while (left) {
+        const uint32_t k = (uint32_t)std::min<uint64_t>(left, max_chunks * SOL_CHUNK);
+        const int rc = sol_render_impl(s, f, k, seed, false);
+        if (rc != SOL_OK) return rc;
+        f += k; left -= k;
+      }
+      return SOL_OK;
+    }
+  }
   // Background blocks - the tail of the work order - are not traced: their sums are written by sol_fill_background_kernel. Counted
   // renders trace everything (their counters describe the whole algorithm; the creation probes are counted renders).
   P.n_traced_blocks = P.n_local_blocks;
@@ -45,7 +65,7 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   // wavefront variants (2: wave-private pool, 3: two-kernel wavefront; bit-identical images) exist in -DSOL_AB_KERNELS builds for
   // A/B runs: they raise the search's lane occupancy (0.45 -> 0.67-0.73) but pay for it in state traffic, refill stalls and
   // per-round tails (MI355X, C3, 128 spp: v1 997, v2 905, v3 684 Msamples/s when they were last compared).
-  if (version != 1 && s->strict_triangles) return sol_fail(SOL_EINVAL, "kernel variant %d does not implement the consistency rule of scenes with needle triangles", version);
+  if (version != 1 && version != 4 && s->strict_triangles) return sol_fail(SOL_EINVAL, "kernel variant %d does not implement the consistency rule of scenes with needle triangles", version);
 #ifndef SOL_AB_KERNELS
   if (version != 1) return sol_fail(SOL_EINVAL, "kernel variant %d exists only in -DSOL_AB_KERNELS builds of the library", version);
   int bpc = sol_render_blocks_per_cu(version, count, s->has_medium, s->strict_triangles);
@@ -58,7 +78,10 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   if (grid > need_blocks) grid = need_blocks;
   P.total_threads = grid * SOL_WG;
   uint32_t lds_depth = (uint32_t)SOL_LDS_STACK;
+  uint32_t stack_need = s->tree_depth;  // dwords of traversal stack a search of this scene can use
 #ifdef SOL_AB_KERNELS
+  // (swap_min: lanes waiting before an exchange pass of the search loop; 64 = only when the wave would otherwise leave for the service block, the best setting measured)
+  if (version == 4) { lds_depth = (uint32_t)sol_pool4_lds_stack_depth(); stack_need = s->packed_depth; P.swap_min = s->pool_swap_min ? s->pool_swap_min : 64u; }
   if (version == 3) lds_depth = (uint32_t)sol_wf_lds_stack_depth();
   if (version == 3) {
     // one global pool: enough slots that the trace kernel has >= 16 rays per resident lane, never more than the items
@@ -105,7 +128,7 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   }
 #endif
   // spill stack only when the tree can out-grow the LDS stack
-  size_t spill_words = s->tree_depth > lds_depth ? (size_t)P.total_threads * (s->tree_depth - lds_depth) : 16;
+  size_t spill_words = stack_need > lds_depth ? (size_t)P.total_threads * (stack_need - lds_depth) : 16;
   if (spill_words > s->spill_words) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->spill) hipFree(s->spill);
@@ -123,7 +146,16 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   P.stage_at = P.n_chunks * P.n_local_blocks * 64u;  // right behind the chunk sums (of every block, traced or not)
   size_t stage_floats = 0;
   const int fine_tail = s->fine_tail >= 0 ? s->fine_tail : s->fine_tail_auto;
-  if (version == 1 && !count && fine_tail > 0) {
+  if (version == 4) {  // every pair (block, chunk) is handed out sample by sample: the staging area holds the whole launch
+    const uint64_t pairs = (uint64_t)P.n_chunks * P.n_traced_blocks;
+    const uint64_t total = pairs * 64u * SOL_CHUNK;
+    if (total > SOL_MAX_ITEMS || (uint64_t)P.stage_at + total > 0xFFFFFFFFull) return sol_fail(SOL_EINVAL, "too many work items in one call (%llu): split the sample range", (unsigned long long)total);
+    stage_floats = (size_t)total * 3u;
+    P.n_coarse = 0;
+    P.n_items = (uint32_t)total;
+    // items per reservation of a wave's reservoir: a whole pair (1024 samples) when every resident wave gets at least 16 of them, else 64
+    P.pool_slots = total >= (uint64_t)(P.total_threads / 64u) * 1024u * 16u ? 1024u : 64u;
+  } else if (version == 1 && !count && fine_tail > 0) {
     const uint32_t rest = P.n_traced_blocks - std::min(P.n_traced_blocks, s->S.n_first);
     const uint32_t pairs = std::min<uint32_t>(rest, (uint32_t)(((uint64_t)fine_tail * (P.total_threads / 64u) + 3u) / 4u));
     const uint64_t total = items - (uint64_t)pairs * 64u + (uint64_t)pairs * 64u * SOL_CHUNK;
@@ -135,7 +167,7 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   }
   // v1 writes every chunk sum into `partial` (also when the call has a single chunk); v2 / v3 add a single chunk straight
   // into the accumulator
-  const bool via_partial = version == 1 || P.n_chunks > 1;
+  const bool via_partial = version == 1 || version == 4 || P.n_chunks > 1;
   if (via_partial) {
     size_t need = slots3 * P.n_chunks + stage_floats;
     if (need > s->partial_floats) {
@@ -187,7 +219,7 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
     }
     if (P.n_items > 0)
       HIP_TRY(sol_launch_render(version, s->S, s->dscene, P, s->acc, s->partial, s->work, s->spill, s->pool, s->counters, grid, count,
-                                s->has_medium, s->tree_depth > (uint32_t)SOL_LDS_STACK, s->stream));
+                                s->has_medium, stack_need > lds_depth, s->stream));
     if (P.n_traced_blocks != P.n_local_blocks) HIP_TRY(sol_launch_fill_background(s->dscene, P, s->partial, s->stream));
   }
   if (s->timing) { HIP_TRY(hipEventRecord(s->ev_stop, s->stream)); s->timed_launches++; }

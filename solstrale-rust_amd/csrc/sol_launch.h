@@ -13,6 +13,11 @@ hipError_t sol_launch_stage_resolve(const DevScene* dS, const RenderParams& P, f
 hipError_t sol_launch_fill_background(const DevScene* dS, const RenderParams& P, float* partial, hipStream_t stream);
 hipError_t sol_launch_debug_path(const DevScene& S, const RenderParams& P, uint32_t px, uint32_t py, uint32_t s, uint32_t* spill,
                                  float* out, uint32_t max_rows, bool medium, hipStream_t stream);
+// ---- sol_pool.hip: version 4, the pool kernel (a second path context per lane in LDS, handed out wave-wide; sample-granular work items) ----
+hipError_t sol_launch_pool4(const DevScene& S, const DevScene* dS, const RenderParams& P, float* partial, uint32_t* work, uint32_t* spill, uint32_t grid,
+                            bool medium, bool may_spill, DevCounters* cnt, hipStream_t stream);
+int sol_pool4_blocks_per_cu(bool medium, bool strict);
+int sol_pool4_lds_stack_depth();
 // ---- sol_wavefront.hip (-DSOL_AB_KERNELS builds only) ----
 // version 2: wave-private wavefront over a pool of path slots
 hipError_t sol_launch_pool(const DevScene& S, const RenderParams& P, float* acc, float* partial, uint32_t* work, uint32_t* spill, void* pool,

@@ -166,7 +166,9 @@ __global__ void __launch_bounds__(256) sol_stage_resolve_kernel(const DevScene* 
   if (!decode_item_ordered(*Sp, P, P.n_coarse + i, it)) return;
   f3 sum = mk3(0.f, 0.f, 0.f);
   const float* a = partial + ((size_t)P.stage_at + (size_t)i * SOL_CHUNK) * 3;
-  for (uint32_t k = 0; k < P.fine_count; ++k) sum = sum + mk3(a[3 * k], a[3 * k + 1], a[3 * k + 2]);
+  // (the fine tail lies in the last chunk; the pool kernel hands out EVERY chunk sample by sample: whole chunks but the last)
+  const uint32_t count = it.chunk + 1u == P.n_chunks ? P.fine_count : (uint32_t)SOL_CHUNK;
+  for (uint32_t k = 0; k < count; ++k) sum = sum + mk3(a[3 * k], a[3 * k + 1], a[3 * k + 2]);
   float* o = partial + ((size_t)it.chunk * (P.n_local_blocks * 64u) + it.slot) * 3;
   o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
 }
@@ -275,6 +277,9 @@ static hipError_t launch_v1_any(const DevScene* dS, const RenderParams& P, float
 hipError_t sol_launch_render(int version, const DevScene& S, const DevScene* dS, const RenderParams& P, float* acc, float* partial, uint32_t* work,
                              uint32_t* spill, void* pool, DevCounters* cnt, uint32_t grid, bool count, bool medium, bool may_spill,
                              hipStream_t stream) {
+#ifdef SOL_AB_KERNELS
+  if (version == 4) return sol_launch_pool4(S, dS, P, partial, work, spill, grid, medium, may_spill, count ? cnt : nullptr, stream);  // (sol_pool.hip)
+#endif
   if (version == 1)
     return S.tri_delta > 0.0f ? launch_v1_any<true>(dS, P, acc, partial, work, spill, cnt, grid, count, medium, may_spill, stream)
                               : launch_v1_any<false>(dS, P, acc, partial, work, spill, cnt, grid, count, medium, may_spill, stream);
@@ -292,6 +297,9 @@ static int blocks_per_cu(K kernel) {
   return n;
 }
 int sol_render_blocks_per_cu(int version, bool count, bool medium, bool strict) {
+#ifdef SOL_AB_KERNELS
+  if (version == 4) return sol_pool4_blocks_per_cu(medium, strict);
+#endif
   if (version == 1) {  // (the SPILL = false builds need no more registers or LDS than these)
     if (strict) {
       if (count) return medium ? blocks_per_cu(sol_render_kernel<true, true, true, true>) : blocks_per_cu(sol_render_kernel<true, false, true, true>);

@@ -59,6 +59,7 @@ struct SolDevOverrides {
   int switch_below = -1;         // SOL_SWITCH (-1: default)
   int max_bpc = -1;              // SOL_MAX_BPC
   int fine_tail = -2;            // SOL_FINE_TAIL (-2: not set)
+  int pool_swap_min = 0;         // SOL_POOL_SWAP (pool kernel: RenderParams::swap_min; 0: the default)
   int pool_slots = 0, wf_slots = 0, wf_min_items = -1;  // SOL_POOL_SLOTS / SOL_WF_SLOTS / SOL_WF_MIN_ITEMS (v2 / v3)
   std::string rccl_lib;          // SOL_RCCL_LIB: the communication library to dlopen instead of librccl.so.1 (tests)
   bool verbose = false;          // SOL_VERBOSE
@@ -71,6 +72,7 @@ struct DevTree {
   DWide* wides = nullptr; uint32_t* leaf_refs = nullptr; DTri* tris = nullptr; DTriShade* tri_shade = nullptr; DQuad* quads = nullptr;
   DSphere* spheres = nullptr; DNode* nodes = nullptr; DMedium* mediums = nullptr; uint32_t* lights = nullptr;
   uint32_t emin = 1, depth = 0, root = 0, light0 = 0;
+  uint32_t n_wide = 0, packed_depth = 0;  // wide nodes; stack bound with one-dword node groups (the pool kernel, sol_pool.hip)
   std::vector<uint32_t> old_tri, old_sphere, old_quad;  // device index -> index in the caller's arrays
   void release() {
     void* p[] = {wides, leaf_refs, tris, tri_shade, quads, spheres, nodes, mediums, lights};
@@ -119,6 +121,8 @@ struct SolScene {
   bool has_medium = false;
   bool strict_triangles = false;  // the scene has needle triangles: the STRICT kernel variants (sol_render.hip)
   uint32_t tree_depth = 0;
+  uint32_t n_wide = 0, packed_depth = 0;  // (DevTree) wide nodes of the world tree; stack bound of a search with one-dword node groups
+  uint32_t pool_swap_min = 0;             // SOL_POOL_SWAP (pool kernel, RenderParams::swap_min; 0: the default)
   int rank = 0, world = 1;
   uint32_t blocks_x = 0, blocks_y = 0, n_local_blocks = 0;
   int n_cu = 0;

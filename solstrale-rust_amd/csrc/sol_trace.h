@@ -449,7 +449,11 @@ DEV void prim_test(const DevScene& S, Trav& t, const Stack& st, uint32_t kind, u
 // Part 1 of a step of a 7-wide search, for a lane without pending primitives: takes the nearest child of the lane's node group
 // (popping a group first when its own is used up), pushes the rest of the group, fetches that node (64 bytes) and tests its seven
 // child boxes: a new node group and a new primitive group.
-template <bool COUNT>
+// PACK: node groups go on the stack as ONE dword - base_inner in 17 bits (trees below 2^17 wide nodes: SOL_PACK_MAX_NODES), the node's
+// inner mask in 7, the ordered hit bits in 8 (bit p stands for slot p ^ octant: slots 0..6, positions 0..7) - instead of (g0, meta word):
+// half the LDS per level, which is what the pool kernel (sol_pool.hip) pays its path contexts with. A popped group gets its inner mask
+// back in the meta word's place; the other fields of the meta word are read only between a node's test and its primitives, never after a pop.
+template <bool COUNT, bool PACK = false>
 DEV void wide_visit(Trav& t, const Stack& st, Counters& cnt) {
   const uint32_t oct = t.oct;
 #if SOL_FETCH_PRIO
@@ -457,15 +461,25 @@ DEV void wide_visit(Trav& t, const Stack& st, Counters& cnt) {
 #endif
   uint32_t g0 = t.g0, g1 = t.g1;
   if ((g0 >> 24) == 0u) {  // (a running search without pending primitives has a group here or on the stack)
-    stack_pop2(st, t.sp, g0, g1);
+    if (PACK) {
+      const uint32_t e = stack_pop(st, t.sp);
+      g0 = (e & (SOL_PACK_MAX_NODES - 1u)) | (e & 0xFF000000u);
+      g1 = ((e >> 17) & 0x7Fu) << 15;
+    } else {
+      stack_pop2(st, t.sp, g0, g1);
+    }
   }
   const uint32_t p = (uint32_t)__builtin_ctz(g0 >> 24);  // nearest: lowest bit in visit order
   const uint32_t slot = p ^ oct;
   g0 &= ~(1u << (24u + p));
   const uint32_t idx = (g0 & SOL_WIDE_MAX_INDEX) + __popc(__builtin_amdgcn_ubfe(g1, 15u, slot));  // rank among the node's inner children: imask bits below `slot`
   if ((g0 >> 24) != 0u) {  // siblings left: one stack entry for all of them
-    stack_push(st, t.sp, g0);
-    stack_push(st, t.sp, g1);
+    if (PACK) {
+      stack_push(st, t.sp, (g0 & (0xFF000000u | (SOL_PACK_MAX_NODES - 1u))) | (((g1 >> 15) & 0x7Fu) << 17));
+    } else {
+      stack_push(st, t.sp, g0);
+      stack_push(st, t.sp, g1);
+    }
     if (COUNT) cnt.max_stack = max(cnt.max_stack, (uint32_t)t.sp);
   }
   const float4* wp = reinterpret_cast<const float4*>(st.wides + idx);
@@ -588,13 +602,13 @@ DEV void medium_step(const DevScene& S, Trav& t, const Stack& st, const Rng& rng
 // visits per step, while a wave whose lanes are spread over nodes and primitives pays for both parts anyway. The votes on the
 // step's shape (does any lane hold primitives? are they postponed?) are taken by the whole wave once, not inside the divergent
 // region of the searching lanes (MI355X, 64 spp, ms: C3 69.57 -> 68.85, C2 44.0 -> 43.45, C1 10.37 -> 10.30).
-template <bool COUNT, bool MEDIUM, bool STRICT = false>
+template <bool COUNT, bool MEDIUM, bool STRICT = false, bool PACK = false>
 DEV void trav_step_wave(const DevScene& S, Trav& t, bool act, const Stack& st, const Rng& rng, uint32_t depth, Counters& cnt) {
   // (MEDIUM) a lane inside a medium test rests its world search: no node visit, no primitive of its group, until the test is over
   const bool world = !MEDIUM || t.m.phase == 0u;
   if (act) {
     phase_tick<COUNT>(cnt, 0);
-    if (world && (t.pg >> 24) == 0u) wide_visit<COUNT>(t, st, cnt);
+    if (world && (t.pg >> 24) == 0u) wide_visit<COUNT, PACK>(t, st, cnt);
   }
   const bool has_prim = act && world && (t.pg >> 24) != 0u;
   const bool has_inner = act && world && !has_prim && ((t.g0 >> 24) != 0u || t.sp != t.sp_base);

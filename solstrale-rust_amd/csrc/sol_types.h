@@ -30,6 +30,7 @@
                                  // (0, 1) / (1, 3): C3 70.6 / 70.0 / 69.4, C2 44.6 / 44.3 / 43.8, C1 10.56 / - / 10.39; the service block at 1 or 2 as
                                  // well: C3 70.3 (slower)
 #endif
+#define SOL_PACK_MAX_NODES (1u << 17)  // trees below this many wide nodes can keep their node groups as one stack dword (sol_trace.h, wide_visit<PACK>)
 #define SOL_CHUNK 16        // samples per work item; fixed so that summation order never depends on the partition
 #define SOL_TILE 8          // 8x8-pixel blocks = one wave's worth of adjacent work items
 #define SOL_POOL_MAX 1024   // path slots per wave in the pool kernel (u16 queue entries: 2 KiB of LDS per wave)
@@ -215,6 +216,7 @@ struct RenderParams {
   uint32_t n_items;          // n_chunks * n_traced_blocks * 64
   uint32_t total_threads;    // grid * SOL_WG (spill stack stride)
   uint32_t pool_slots;       // pool kernel: path slots per wave (multiple of 64, <= SOL_POOL_MAX)
+  uint32_t swap_min;         // pool kernel (sol_pool.hip): lanes whose search is over exchange it for a ready ray of the pool once this many wait
   uint32_t switch_below;     // v1: a wave leaves the search loop for shading once fewer than this many of its live lanes
                              // (in 64ths) are still searching and some lane waits; 0 = search until every lane is done
   // v1 writes every item's sum into the `partial` buffer: chunk sums at [chunk][slot], and behind them (from RGB triple stage_at)

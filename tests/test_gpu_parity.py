@@ -129,8 +129,11 @@ def test_wavefront_ab_kernels_are_bit_identical():
     """The staged wavefront forms of the path (north star: "ballot/prefix compaction of active-ray queues into generate /
     intersect / shade stages") live in the A/B build of the library only (_build_ab/, -DSOL_AB_KERNELS: kernel 2 = wave-private
     pool with an LDS ray queue, 3 = separate shade and trace kernels): measured slower than the in-register search/service switch
-    of the product kernel, kept as variants. Their frames, and the A/B library's own kernel 1, must equal the
-    product library's frames bit for bit; the product library itself refuses 2 and 3."""
+    of the product kernel, kept as variants; so does kernel 4, the POOL kernel of round 5 (csrc/sol_pool.hip: a second path
+    context per lane in LDS, handed out wave-wide; one-dword stack entries; sample-granular work items - measured slower,
+    profiles/r05_pool_kernel_ab.txt). Their frames, and the A/B library's own kernel 1, must equal the product library's frames bit for
+    bit - on the sphere scene, the atrium, the heterogeneous atrium (needle triangles: the STRICT variants) and the reference's test scene
+    (constant medium), at a ragged frame size; the product library itself refuses 2, 3 and 4."""
     import json
     import subprocess
     import sys
@@ -139,15 +142,15 @@ def test_wavefront_ab_kernels_are_bit_identical():
     want = frame_crc.crcs([1])
     ab_dir = os.path.join(os.path.dirname(_abi.BUILD_DIR), "_build_ab")
     assert os.path.exists(os.path.join(ab_dir, "libsolstrale_hip.so")), "the A/B library is missing: __graft_entry__.build() makes it"
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "frame_crc.py"), "1", "2", "3"],
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "frame_crc.py"), "1", "2", "3", "4"],
                        env=dict(os.environ, SOLSTRALE_BUILD_DIR=ab_dir), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     got = json.loads(r.stdout.strip().splitlines()[-1])
     for key, crc in got.items():
         assert crc == want[key.split("/")[0] + "/1"], (key, got, want)
-    assert len(got) == 3 * len(want)
+    assert len(got) == 4 * len(want) - 2  # (kernels 2 and 3 do not implement the needle rule: no frames of the heterogeneous atrium)
     with DeviceScene(scenes.cornell_box(RenderConfig(16, 16, 1))) as ds:
-        for k in (2, 3):
+        for k in (2, 3, 4):
             with pytest.raises(DeviceError) as e:
                 ds.set_option(_abi.OPT_KERNEL, k)
             assert e.value.code == _abi.SOL_EINVAL and "SOL_AB_KERNELS" in str(e.value)
