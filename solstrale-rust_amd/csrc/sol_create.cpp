@@ -1034,9 +1034,14 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     // The fine tail takes an item fetch per SAMPLE (a dependent load, three integer divisions: ~2 us): worth it where a sample
     // is long. MI355X, 1080p x 64 spp, ms with 0 / 1 / 2 whole items per lane in the tail: C3 (38 node visits per sample) 76.5 /
     // 75.5 / 74.4, C2 (22) 45.5 / 45.7 / 46.3, C1 (2) 10.5 / 11.2 / 11.8.
+    // Round 5, re-measured on the round-4 trees and kernel (profiles/r05_fine_tail_sweep.txt; 64 spp, ms with a tail of 0 / 2 / 4 / 8 / 16 whole
+    // items per lane): C1 (2 node visits per sample) 9.09 / 9.07 / 9.66 / 9.74 / 9.65, test scene (8) 9.75 / 8.33 / 8.39 / 8.28 / 8.16, C5 (12) 37.9 /
+    // 38.2 / 38.8 / 38.2 / 38.3, C2 (19) 33.7 / 32.5 / 31.5 / 31.4 / 31.3, C3 (36) 62.5 / 60.5 / 60.5 / 60.6 / 60.6: the per-sample fetch no longer
+    // costs what it did (the reservoir, the work order), a short launch of long paths gains most. By the probe's node visits per sample:
+    // below 5 none, 15 .. 30 eight whole items per lane, else two.
     if (s->stats.samples > 0) {
       const double vps = (double)s->stats.node_visits / (double)s->stats.samples;
-      s->fine_tail_auto = vps >= 30.0 ? 8 : 0;
+      s->fine_tail_auto = vps < 5.0 ? 0 : (vps >= 15.0 && vps < 30.0) ? 32 : 8;
     }
     s->stats = SolStats{};
     if ((rc = sol_clear(s)) || (rc = sol_rebuild_order(s))) return rc;
