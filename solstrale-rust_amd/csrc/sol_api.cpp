@@ -56,6 +56,7 @@ SolDevOverrides sol_dev_overrides() {
   o.max_bpc = num("SOL_MAX_BPC", -1);
   o.fine_tail = std::max(-2, num("SOL_FINE_TAIL", -2));
   o.pool_swap_min = std::max(0, num("SOL_POOL_SWAP", 0));
+  o.probe_radii = num("SOL_PROBE_RADII", -1);
   o.pool_slots = std::max(0, num("SOL_POOL_SLOTS", 0));
   o.wf_slots = std::max(0, num("SOL_WF_SLOTS", 0));
   o.wf_min_items = num("SOL_WF_MIN_ITEMS", -1);

@@ -51,6 +51,7 @@ struct SolDeviceTree {
   float split_area_ratio = 1.f;  // summed box area of the references after / before pre-splitting (also when the splits were not kept)
   uint32_t reinsertion_moves = 0;            // sub-trees moved by the reinsertion rounds
   double area_before = 0., area_after = 0.;  // summed surface area of the binary tree's inner nodes before / after them
+  float collapse_cost = 0.f;                 // the collapse's surface-area cost of the whole tree (C(root, 1): node cost x node areas + primitive areas)
 };
 
 // Builds the 7-wide tree over `prims` (host memory, n >= 1, every reference at most once) on the current HIP device.
@@ -58,5 +59,13 @@ struct SolDeviceTree {
 // (WideBuilder::exponent_min); counts: sizes of the triangle / sphere / quad arrays; tris: the triangle records (counts[0] of them; the
 // vertices pre-splitting clips, may be null: no splitting); ploc_radius: neighbours searched to each side in a clustering round
 // (0: the default, 16). False + message on failure.
+// The same build in two halves (a caller with several candidates compares SolDeviceTree::collapse_cost before it pays for an emission):
+// prepare fills the split / reinsertion / cost fields of `out` and hands back a handle; emit fills the rest; release frees the handle.
+struct SolDeviceBuild;
+bool sol_build_world_tree_prepare(const SolBuildPrim* prims, uint32_t n, const float root_box[6], float pad, uint32_t emin, const uint32_t counts[3],
+                                  const DTri* tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, SolDeviceTree& out, SolDeviceBuild** handle,
+                                  std::string& err);
+bool sol_build_world_tree_emit(SolDeviceBuild* handle, SolDeviceTree& out, std::string& err);
+void sol_build_world_tree_release(SolDeviceBuild* handle);
 bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n, const float root_box[6], float pad, uint32_t emin, const uint32_t counts[3],
                                  const DTri* tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, SolDeviceTree& out, std::string& err);

@@ -28,6 +28,9 @@
 //      layout DWide needs.
 // None of this is on the per-sample path. The only library call is rocPRIM's sort / scan (plain primitives).
 #include <hip/hip_runtime.h>
+
+#include <functional>
+#include <memory>
 #include <chrono>
 
 #include <algorithm>
@@ -518,10 +521,12 @@ __global__ void __launch_bounds__(BT) k_reins_verify(uint32_t n_nodes, const uin
   ok[x] = mine ? 1 : 0;  // (read-only kernel as far as the tree goes: the moves are carried out by the next one)
 }
 __global__ void __launch_bounds__(BT) k_reins_apply(uint32_t n_nodes, uint32_t* __restrict__ parent, uint32_t* __restrict__ left, uint32_t* __restrict__ right,
-                                                     const uint32_t* __restrict__ best_out, const uint8_t* __restrict__ ok, uint32_t* __restrict__ n_moved) {
+                                                     const uint32_t* __restrict__ best_out, const uint8_t* __restrict__ ok, uint32_t* __restrict__ n_moved,
+                                                     uint32_t* __restrict__ left_from) {
   const uint32_t x = blockIdx.x * BT + threadIdx.x;
   if (x >= n_nodes || !ok[x]) return;
   const uint32_t y = best_out[x], p = parent[x], g = parent[p];
+  left_from[x] = g;  // (k_refit_mark: the boxes from x's old place upwards change too)
   const uint32_t s = left[p] == x ? right[p] : left[p];
   // s takes p's place under g
   if (left[g] == p) left[g] = s; else right[g] = s;
@@ -535,26 +540,61 @@ __global__ void __launch_bounds__(BT) k_reins_apply(uint32_t n_nodes, uint32_t* 
   parent[y] = p;
   atomicAdd(n_moved, 1u);
 }
-// boxes of the inner nodes, bottom-up (the second child to arrive computes its parent)
-__global__ void __launch_bounds__(BT) k_refit(uint32_t n_leaves, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
-                                               float* __restrict__ nbox, uint32_t* __restrict__ arrived, double* __restrict__ cost) {
+// ---- refit after a reinsertion round: only what the moves touched (round 5) --------------------------------------------------------
+// A move changes the boxes on two paths to the root: from p (x's parent, now between the target and the target's old parent) and from g
+// (p's old parent, which lost the sub-tree). Round 4 recomputed every box of the tree after every round (bottom-up from all leaves, the second
+// child to arrive computing its parent) - 3.3 ms for the 2.2 M nodes of C5, 9 times per tree, a third of scene creation's GPU time. Now: (1) every move marks its two paths DIRTY
+// (a walk stops at a node another walk has marked: that walk marks the rest); (2) every dirty node counts its CLEAN children as arrived -
+// a dirty node whose children are both clean is a start; (3) walks go up from the starts, the second arrival at a node computes it (the
+// arrival pattern of the full refit - a release fence before the arrival, an acquire fence after it -, on the dirty set only). Boxes are unions - exact -, so the result is the full refit's, bit for bit.
+__global__ void __launch_bounds__(BT) k_refit_mark(uint32_t n_nodes, const uint32_t* __restrict__ parent, const uint8_t* __restrict__ ok,
+                                                    const uint32_t* __restrict__ left_from, uint32_t* __restrict__ dirty) {
+  const uint32_t x = blockIdx.x * BT + threadIdx.x;
+  if (x >= n_nodes || !ok[x]) return;
+  for (int k = 0; k < 2; ++k) {
+    uint32_t m = k == 0 ? parent[x] : left_from[x];
+    int steps = 0;
+    while (m != NONE && ++steps < 4096) {
+      if (atomicExch(&dirty[m], 1u) != 0u) break;
+      m = parent[m];
+    }
+  }
+}
+__global__ void __launch_bounds__(BT) k_refit_prepare(uint32_t n_nodes, uint32_t n_leaves, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                       uint32_t* __restrict__ dirty, uint32_t* __restrict__ arrived) {
+  const uint32_t m = blockIdx.x * BT + threadIdx.x;
+  if (m >= n_nodes || m < n_leaves || dirty[m] == 0u) return;
+  // (dirty[] of the children is 0 or 1 here: the values 2 are written to other nodes' own entries only, and read by nobody in this launch)
+  const uint32_t clean = (dirty[left[m]] == 0u ? 1u : 0u) + (dirty[right[m]] == 0u ? 1u : 0u);
+  arrived[m] = clean;
+}
+__global__ void __launch_bounds__(BT) k_refit_starts(uint32_t n_nodes, uint32_t n_leaves, uint32_t* __restrict__ dirty, const uint32_t* __restrict__ arrived) {
+  const uint32_t m = blockIdx.x * BT + threadIdx.x;
+  if (m >= n_nodes || m < n_leaves || dirty[m] == 0u) return;
+  if (arrived[m] == 2u) dirty[m] = 2u;  // both children clean: a walk starts here
+}
+__global__ void __launch_bounds__(BT) k_refit_walk(uint32_t n_nodes, uint32_t n_leaves, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left,
+                                                    const uint32_t* __restrict__ right, float* __restrict__ nbox, uint32_t* __restrict__ dirty, uint32_t* __restrict__ arrived) {
   const uint32_t i = blockIdx.x * BT + threadIdx.x;
-  uint32_t m = i < n_leaves ? parent[i] : NONE;
-  double sum = 0.;
+  if (i >= n_nodes || i < n_leaves || dirty[i] != 2u) return;
+  uint32_t m = i;
   int steps = 0;
-  while (m != NONE && ++steps < 4096) {
-    // release (the boxes this thread wrote are visible before its arrival is) / acquire (the second to arrive sees the first one's boxes): the
-    // two halves of what a __threadfence() on either side did in full, twice (C3: 1.33 -> 0.75 ms per launch, 27 launches per scene)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (atomicAdd(&arrived[m], 1u) == 0u) break;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  for (;;) {
     const float *ba = nbox + (size_t)left[m] * 6, *bb = nbox + (size_t)right[m] * 6;
     float* bo = nbox + (size_t)m * 6;
     for (int k = 0; k < 6; k += 2) { bo[k] = fminf(ba[k], bb[k]); bo[k + 1] = fmaxf(ba[k + 1], bb[k + 1]); }
-    sum += (double)box_area(bo);
+    dirty[m] = 0u;  // (clean again for the next round; nobody reads this entry any more in this launch: its parent's count was taken in k_refit_prepare)
     m = parent[m];
+    if (m == NONE || ++steps >= 4096) break;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (this thread's boxes first, then its arrival; the second arrival acquires)
+    if (atomicAdd(&arrived[m], 1u) != 1u) break;        // the other dirty child's walk will do this node
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  // one atomic per wave, not per thread: 130 000 double atomics on one address were 1.3 of this kernel's 1.35 ms (C3), 27 launches per tree
+}
+// Summed surface area of the inner nodes (SolSceneInfo: what the reinsertion rounds bought).
+__global__ void __launch_bounds__(BT) k_area_sum(uint32_t n_nodes, uint32_t n_leaves, const float* __restrict__ nbox, double* __restrict__ cost) {
+  const uint32_t m = blockIdx.x * BT + threadIdx.x;
+  double sum = (m < n_nodes && m >= n_leaves) ? (double)box_area(nbox + (size_t)m * 6) : 0.;
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
   if ((threadIdx.x & 63u) == 0u && sum > 0.) atomicAdd(cost, sum);
 }
@@ -590,7 +630,7 @@ __global__ void __launch_bounds__(BT) k_collapse_cost(uint32_t n_leaves, const u
   }
   uint32_t m = parent[i];
   while (m != NONE) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (as in k_refit: this thread's table first, then its arrival)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (as in k_refit_walk: this thread's table first, then its arrival)
     if (atomicAdd(&arrived[m], 1u) == 0u) return;  // the sibling's thread will do this node
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const Dp dl = dp[left[m]], dr = dp[right[m]];
@@ -854,10 +894,35 @@ struct Scratch {  // device allocations of one build, freed on every path
     if (e_ != hipSuccess) { err = std::string("launch of " #kernel ": ") + hipGetErrorString(e_); return false; } \
   } while (0)
 
+// A build in two halves: everything up to the collapse's surface-area cost of the tree (which is what a caller with several candidates
+// compares), and the emission of the wide nodes + the download of the result. The device memory of the first half lives in the handle.
+struct SolDeviceBuild {
+  std::shared_ptr<Scratch> scratch;
+  std::function<bool(SolDeviceTree&, std::string&)> emit;
+};
+void sol_build_world_tree_release(SolDeviceBuild* b) { delete b; }
+bool sol_build_world_tree_emit(SolDeviceBuild* b, SolDeviceTree& out, std::string& err) {
+  if (!b || !b->emit) { err = "device tree build: nothing prepared"; return false; }
+  const bool ok = b->emit(out, err);
+  b->emit = nullptr;
+  b->scratch.reset();
+  return ok;
+}
 bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n_in, const float root_box[6], float pad, uint32_t emin, const uint32_t counts_in[3],
                                  const DTri* tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, SolDeviceTree& out, std::string& err) {
+  SolDeviceBuild* b = nullptr;
+  if (!sol_build_world_tree_prepare(prims, n_in, root_box, pad, emin, counts_in, tris, split, ploc_radius, stream, out, &b, err)) return false;
+  const bool ok = sol_build_world_tree_emit(b, out, err);
+  sol_build_world_tree_release(b);
+  return ok;
+}
+bool sol_build_world_tree_prepare(const SolBuildPrim* prims, uint32_t n_in, const float root_box[6], float pad, uint32_t emin, const uint32_t counts_in[3],
+                                  const DTri* tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, SolDeviceTree& out, SolDeviceBuild** handle,
+                                  std::string& err) {
+  *handle = nullptr;
   if (n_in == 0 || n_in > (SOL_WIDE_MAX_INDEX >> 1)) { err = "device tree build: primitive count out of range"; return false; }
-  Scratch S;
+  std::shared_ptr<Scratch> Sp = std::make_shared<Scratch>();
+  Scratch& S = *Sp;
   uint32_t n = n_in;
   uint32_t counts[3] = {counts_in[0], counts_in[1], counts_in[2]};
   SolBuildPrim* d_prims;
@@ -1046,14 +1111,25 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n_in, const
     B_TRY(S.get(&in_key, n_nodes)); B_TRY(S.get(&ok, n_nodes));
     B_TRY(S.get(&lock, n_nodes)); B_TRY(S.get(&best_out, n_nodes)); B_TRY(S.get(&best_pivot, n_nodes)); B_TRY(S.get(&best_gain, n_nodes)); B_TRY(S.get(&n_moved, 1)); B_TRY(S.get(&cost, 1));
     const uint32_t gn = (n_nodes + BT - 1) / BT;
-    auto refit = [&](double& total) -> bool {
-      if (hipMemsetAsync(arrived, 0, (size_t)n_nodes * 4, stream) != hipSuccess || hipMemsetAsync(cost, 0, 8, stream) != hipSuccess) return false;
-      hipLaunchKernelGGL(k_refit, dim3(nb), dim3(BT), 0, stream, n, parent, left, right, nbox, arrived, cost);
+    uint32_t* dirty;
+    B_TRY(S.get(&dirty, n_nodes));
+    B_TRY(hipMemsetAsync(dirty, 0, (size_t)n_nodes * 4, stream));
+    // (the clustering leaves every box valid: k_merge computes a new node's box from its children's)
+    auto area = [&](double& total) -> bool {
+      if (hipMemsetAsync(cost, 0, 8, stream) != hipSuccess) return false;
+      hipLaunchKernelGGL(k_area_sum, dim3(gn), dim3(BT), 0, stream, n_nodes, n, nbox, cost);
       if (hipGetLastError() != hipSuccess) return false;
       if (hipMemcpyAsync(&total, cost, 8, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
       return hipStreamSynchronize(stream) == hipSuccess;
     };
-    if (!refit(out.area_before)) { err = "device tree build: refit failed"; return false; }
+    auto refit_moved = [&]() -> bool {  // boxes on the paths the round's moves touched (best_pivot: where each moved node left from)
+      hipLaunchKernelGGL(k_refit_mark, dim3(gn), dim3(BT), 0, stream, n_nodes, parent, ok, best_pivot, dirty);
+      hipLaunchKernelGGL(k_refit_prepare, dim3(gn), dim3(BT), 0, stream, n_nodes, n, left, right, dirty, arrived);
+      hipLaunchKernelGGL(k_refit_starts, dim3(gn), dim3(BT), 0, stream, n_nodes, n, dirty, arrived);
+      hipLaunchKernelGGL(k_refit_walk, dim3(gn), dim3(BT), 0, stream, n_nodes, n, parent, left, right, nbox, dirty, arrived);
+      return hipGetLastError() == hipSuccess;
+    };
+    if (!area(out.area_before)) { err = "device tree build: area sum failed"; return false; }
     out.area_after = out.area_before;
     for (int round = 0; round < split.reinsertion_rounds; ++round) {
       const uint32_t stride = (uint32_t)std::max(1, split.reinsertion_stride);
@@ -1065,17 +1141,21 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n_in, const
       B_LAUNCHED(k_reins_lock);
       hipLaunchKernelGGL(k_reins_verify, dim3(gn), dim3(BT), 0, stream, n_nodes, parent, left, right, best_out, best_pivot, best_gain, lock, in_key, ok);
       B_LAUNCHED(k_reins_verify);
-      hipLaunchKernelGGL(k_reins_apply, dim3(gn), dim3(BT), 0, stream, n_nodes, parent, left, right, best_out, ok, n_moved);
+      hipLaunchKernelGGL(k_reins_apply, dim3(gn), dim3(BT), 0, stream, n_nodes, parent, left, right, best_out, ok, n_moved, best_pivot);  // (best_pivot is free once the move is verified: it takes left_from)
       B_LAUNCHED(k_reins_apply);
       uint32_t moved = 0;
       B_TRY(hipMemcpyAsync(&moved, n_moved, 4, hipMemcpyDeviceToHost, stream));
-      double total = 0.;
-      if (!refit(total)) { err = "device tree build: refit failed"; return false; }
+      if (!refit_moved()) { err = "device tree build: refit failed"; return false; }
+      B_TRY(hipStreamSynchronize(stream));
       out.reinsertion_moves += moved;
-      out.area_after = total;
-      if (split.verbose) std::fprintf(stderr, "[solstrale] reinsertion round %d: %u moves, summed inner area %.6g (start %.6g)\n", round, moved, total, out.area_before);
+      if (split.verbose) {
+        double total = 0.;
+        if (!area(total)) { err = "device tree build: area sum failed"; return false; }
+        std::fprintf(stderr, "[solstrale] reinsertion round %d: %u moves, summed inner area %.6g (start %.6g)\n", round, moved, total, out.area_before);
+      }
       if (moved == 0 && stride == 1) break;
     }
+    if (!area(out.area_after)) { err = "device tree build: area sum failed"; return false; }
     B_TRY(hipMemsetAsync(arrived, 0, (size_t)n_nodes * 4, stream));  // (k_collapse_cost counts arrivals again)
     B_TRY(hipMemsetAsync(n_moved, 0, 4, stream));
     uint32_t* bad;
@@ -1092,8 +1172,20 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n_in, const
   // ---- 3. collapse costs ----
   hipLaunchKernelGGL(k_collapse_cost, dim3(nb), dim3(BT), 0, stream, n, parent, left, right, nbox, arrived, dp, split.node_cost);
   B_LAUNCHED(k_collapse_cost);
+  out.collapse_cost = 0.f;
+  if (root_node >= n) B_TRY(hipMemcpyAsync(&out.collapse_cost, &dp[root_node].c[1], 4, hipMemcpyDeviceToHost, stream));
   B_TRY(hipStreamSynchronize(stream));
   dbg("collapse costs done");
+  const bool verbose = split.verbose;
+  const uint32_t counts0 = counts[0], counts1 = counts[1], counts2 = counts[2];
+  uint32_t* const ni0 = new_index[0]; uint32_t* const ni1 = new_index[1]; uint32_t* const ni2 = new_index[2];
+  SolDeviceBuild* b = new SolDeviceBuild;
+  b->scratch = Sp;
+  // (everything the second half needs, by value: device pointers into the handle's scratch memory and a few numbers)
+  b->emit = [=](SolDeviceTree& out, std::string& err) -> bool {
+  const uint32_t counts[3] = {counts0, counts1, counts2};
+  uint32_t* const new_index[3] = {ni0, ni1, ni2};
+  auto dbg = [&](const char* what) { if (verbose) { hipStreamSynchronize(stream); std::fprintf(stderr, "[solstrale]   build: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dbg0).count()); } };
   // ---- 4. emission, level by level ----
   EmitParams P;
   P.prims = d_prims; P.order = order; P.left = left; P.right = right; P.nbox = nbox; P.dp = dp; P.n_leaves = n; P.pad = pad; P.emin = emin;
@@ -1136,5 +1228,8 @@ bool sol_build_world_tree_device(const SolBuildPrim* prims, uint32_t n_in, const
   }
   B_TRY(hipStreamSynchronize(stream));
   dbg("emitted and downloaded");
+  return true;
+  };  // (b->emit)
+  *handle = b;
   return true;
 }

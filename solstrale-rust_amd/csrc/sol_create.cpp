@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sol_build.h"
@@ -34,6 +35,7 @@ struct DeviceSplitInfo {
   float area_ratio = 1.f;
   uint32_t reinsertion_moves = 0;
   double area_before = 0., area_after = 0.;
+  float collapse_cost = 0.f;  // (SolDeviceTree) the collapse's surface-area cost of the tree
 };
 // The world's primitives as the device builder takes them (each once, in the order of their references): collected once per scene,
 // whatever the number of candidate trees.
@@ -42,15 +44,25 @@ static int collect_build_prims(const std::vector<DNode>& bin, uint32_t root_ref,
   if (SOL_REF_KIND(root_ref) == SOL_REF_NODE) {
     SahBuilder col;
     if (!col.collect(bin, root_ref)) return sol_fail(SOL_EINVAL, "the world's primitives cannot be collected (non-finite box or fewer than two)");
-    std::sort(col.prims.begin(), col.prims.end(), [](const SahBuilder::Prim& a, const SahBuilder::Prim& b) { return a.ref < b.ref; });
-    prims.reserve(col.prims.size());
+    // in the order of their references, each once (a shared sub-tree lists its primitives twice): a counting pass per kind instead of a
+    // sort - std::sort of C5's 1.09 M records was 0.08 s of sol_scene_create
+    uint32_t top[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const auto& q : col.prims) top[SOL_REF_KIND(q.ref) & 7u] = std::max(top[SOL_REF_KIND(q.ref) & 7u], SOL_REF_INDEX(q.ref) + 1u);
+    std::vector<int32_t> first[8];
+    for (int k = 0; k < 8; ++k) first[k].assign(top[k], -1);
     for (size_t i = 0; i < col.prims.size(); ++i) {
-      if (i && col.prims[i].ref == col.prims[i - 1].ref) continue;
-      SolBuildPrim p;
-      for (int k = 0; k < 6; ++k) p.box[k] = col.prims[i].box.v[k];
-      p.ref = col.prims[i].ref; p.pad = 0;
-      prims.push_back(p);
+      int32_t& f = first[SOL_REF_KIND(col.prims[i].ref) & 7u][SOL_REF_INDEX(col.prims[i].ref)];
+      if (f < 0) f = (int32_t)i;
     }
+    prims.reserve(col.prims.size());
+    for (int k = 0; k < 8; ++k)
+      for (int32_t f : first[k]) {
+        if (f < 0) continue;
+        SolBuildPrim p;
+        for (int j = 0; j < 6; ++j) p.box[j] = col.prims[(size_t)f].box.v[j];
+        p.ref = col.prims[(size_t)f].ref; p.pad = 0;
+        prims.push_back(p);
+      }
   } else {
     SolBuildPrim p;
     for (int k = 0; k < 6; ++k) p.box[k] = root_box.v[k];
@@ -59,19 +71,38 @@ static int collect_build_prims(const std::vector<DNode>& bin, uint32_t root_ref,
   }
   return SOL_OK;
 }
-static int device_world_tree(const std::vector<SolBuildPrim>& prims, const Box& root_box, float box_pad, const uint32_t counts[3],
-                             const std::vector<DTri>& tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, WideLayout& lay, uint32_t& emin,
-                             DeviceSplitInfo* split_info) {
-  const auto t_dbg0 = std::chrono::steady_clock::now();
-  auto dbg = [&](const char* what) { if (split.verbose) std::fprintf(stderr, "[solstrale] device_world_tree: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dbg0).count()); };
-  emin = WideBuilder::exponent_min(root_box, box_pad);
+// A device build in its two halves (sol_build.h): the binary tree with its collapse cost, kept on the device behind `handle`; then the
+// emission of the wide nodes and their adoption as a host-side layout record.
+struct DevicePrepared {
+  SolDeviceBuild* handle = nullptr;
   SolDeviceTree dt;
+  uint32_t emin = 1;
+  DevicePrepared() = default;
+  DevicePrepared(const DevicePrepared&) = delete;
+  DevicePrepared& operator=(const DevicePrepared&) = delete;
+  ~DevicePrepared() { if (handle) sol_build_world_tree_release(handle); }
+};
+static int device_world_tree_prepare(const std::vector<SolBuildPrim>& prims, const Box& root_box, float box_pad, const uint32_t counts[3], const std::vector<DTri>& tris,
+                                     const SolSplitOptions& split, int ploc_radius, hipStream_t stream, DevicePrepared& pr) {
+  pr.emin = WideBuilder::exponent_min(root_box, box_pad);
   std::string err;
   const bool have_tris = tris.size() == counts[0] && counts[0] > 0;
-  if (!sol_build_world_tree_device(prims.data(), (uint32_t)prims.size(), root_box.v, box_pad, emin, counts, have_tris ? tris.data() : nullptr, split, ploc_radius, stream, dt,
-                                   err))
+  if (!sol_build_world_tree_prepare(prims.data(), (uint32_t)prims.size(), root_box.v, box_pad, pr.emin, counts, have_tris ? tris.data() : nullptr, split, ploc_radius, stream,
+                                    pr.dt, &pr.handle, err))
     return sol_fail(SOL_EDEVICE, "%s", err.c_str());
-  dbg("device build returned");
+  return SOL_OK;
+}
+static int device_world_tree_finish(DevicePrepared& pr, const uint32_t counts[3], const SolSplitOptions& split, WideLayout& lay, uint32_t& emin, DeviceSplitInfo* split_info) {
+  const auto t_dbg0 = std::chrono::steady_clock::now();
+  auto dbg = [&](const char* what) { if (split.verbose) std::fprintf(stderr, "[solstrale] device_world_tree: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dbg0).count()); };
+  emin = pr.emin;
+  SolDeviceTree& dt = pr.dt;
+  std::string err;
+  const bool emitted = sol_build_world_tree_emit(pr.handle, dt, err);
+  sol_build_world_tree_release(pr.handle);
+  pr.handle = nullptr;
+  if (!emitted) return sol_fail(SOL_EDEVICE, "%s", err.c_str());
+  dbg("device build emitted");
   const std::vector<uint32_t> extra_of = std::move(dt.extra_of);
   if (!lay.adopt_device(std::move(dt.nodes), std::move(dt.leaf_refs), dt.new_of_old, dt.depth)) return sol_fail(SOL_EDEVICE, "%s", lay.error.c_str());
   if (split_info) {
@@ -79,6 +110,7 @@ static int device_world_tree(const std::vector<SolBuildPrim>& prims, const Box& 
     split_info->area_ratio = dt.split_area_ratio;
     split_info->split_triangles = dt.split_triangles;
     split_info->reinsertion_moves = dt.reinsertion_moves; split_info->area_before = dt.area_before; split_info->area_after = dt.area_after;
+    split_info->collapse_cost = dt.collapse_cost;
   }
   if (split_info && split.want_boxes) {
     split_info->ref_of_dev = lay.old_of_new[0];
@@ -97,6 +129,13 @@ static int device_world_tree(const std::vector<SolBuildPrim>& prims, const Box& 
   }
   dbg("layout adopted");
   return SOL_OK;
+}
+static int device_world_tree(const std::vector<SolBuildPrim>& prims, const Box& root_box, float box_pad, const uint32_t counts[3],
+                             const std::vector<DTri>& tris, const SolSplitOptions& split, int ploc_radius, hipStream_t stream, WideLayout& lay, uint32_t& emin,
+                             DeviceSplitInfo* split_info) {
+  DevicePrepared pr;
+  if (int rc = device_world_tree_prepare(prims, root_box, box_pad, counts, tris, split, ploc_radius, stream, pr)) return rc;
+  return device_world_tree_finish(pr, counts, split, lay, emin, split_info);
 }
 
 // A triangle's fp32 intersect record: starts at the vertex opposite the longest edge (fp32 arithmetic contract, solstrale_hip.h
@@ -587,17 +626,31 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   // ---- primitives (plain casts) ----
   std::vector<DTri> tris(d->n_triangles);
   std::vector<DTriShade> tshade(d->n_triangles);
-  for (uint32_t i = 0; i < d->n_triangles; ++i) {
-    const SolTriangle& t = d->triangles[i];
-    if (!mat_ok(t.material)) return sol_fail(SOL_EINVAL, "triangle %u: bad material", i);
-    int uo[3];
-    cast_triangle(t, false, tris[i], uo);
-    const float* uvs[3] = {t.uv0, t.uv1, t.uv2};
-    DTriShade& s = tshade[i];
-    s.nx = (float)t.normal[0]; s.ny = (float)t.normal[1]; s.nz = (float)t.normal[2]; s.mat = t.material;
-    s.tx = (float)t.tangent[0]; s.ty = (float)t.tangent[1]; s.tz = (float)t.tangent[2];
-    s.bx = (float)t.bi_tangent[0]; s.by = (float)t.bi_tangent[1]; s.bz = (float)t.bi_tangent[2];
-    s.u0 = uvs[uo[0]][0]; s.v0 = uvs[uo[0]][1]; s.u1 = uvs[uo[1]][0]; s.v1 = uvs[uo[1]][1]; s.u2 = uvs[uo[2]][0]; s.v2 = uvs[uo[2]][1];
+  {
+    // (a million triangles are 0.03 s of casts on one core: split over a few threads above 64 k; every triangle is independent)
+    auto cast_range = [&](uint32_t i0, uint32_t i1, int64_t* bad) {
+      for (uint32_t i = i0; i < i1; ++i) {
+        const SolTriangle& t = d->triangles[i];
+        if (!mat_ok(t.material)) { if (*bad < 0) *bad = i; continue; }
+        int uo[3];
+        cast_triangle(t, false, tris[i], uo);
+        const float* uvs[3] = {t.uv0, t.uv1, t.uv2};
+        DTriShade& s = tshade[i];
+        s.nx = (float)t.normal[0]; s.ny = (float)t.normal[1]; s.nz = (float)t.normal[2]; s.mat = t.material;
+        s.tx = (float)t.tangent[0]; s.ty = (float)t.tangent[1]; s.tz = (float)t.tangent[2];
+        s.bx = (float)t.bi_tangent[0]; s.by = (float)t.bi_tangent[1]; s.bz = (float)t.bi_tangent[2];
+        s.u0 = uvs[uo[0]][0]; s.v0 = uvs[uo[0]][1]; s.u1 = uvs[uo[1]][0]; s.v1 = uvs[uo[1]][1]; s.u2 = uvs[uo[2]][0]; s.v2 = uvs[uo[2]][1];
+      }
+    };
+    const uint32_t nt = d->n_triangles;
+    const uint32_t n_thr = nt >= 65536u ? std::min<uint32_t>(8u, std::max<uint32_t>(1u, std::thread::hardware_concurrency())) : 1u;
+    std::vector<int64_t> bad(n_thr, -1);
+    std::vector<std::thread> pool;
+    for (uint32_t k = 1; k < n_thr; ++k) pool.emplace_back(cast_range, (uint32_t)((uint64_t)nt * k / n_thr), (uint32_t)((uint64_t)nt * (k + 1) / n_thr), &bad[k]);
+    cast_range(0, (uint32_t)((uint64_t)nt / n_thr), &bad[0]);
+    for (auto& th : pool) th.join();
+    for (int64_t b : bad)
+      if (b >= 0) return sol_fail(SOL_EINVAL, "triangle %u: bad material", (uint32_t)b);
   }
   std::vector<DQuad> quads(d->n_quads);
   for (uint32_t i = 0; i < d->n_quads; ++i) {
@@ -619,8 +672,10 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     o.dfs = s.dfs_index; o.mat = s.material; o.pad0 = o.pad1 = 0;
   }
 
+  if (sol_dev_overrides().verbose) std::fprintf(stderr, "[solstrale] create: records cast at %.1f ms\n", 1e3 * seconds_since(t_begin));
   // ---- tree ----
   const float box_pad = box_pad_for(*d);
+  const bool scene_has_needles = sol_scene_has_needles(d) != 0;  // (a pass over every triangle: asked once more here, not once per use)
   // (the 7-wide node test's plane parameters must not overflow: sol_trace.h, wide_node_test; pad = largest |coordinate| * 2^-20)
   if (!(box_pad * 1048576.0f <= 2.7487791e11f)) return sol_fail(SOL_EINVAL, "the scene's coordinates reach beyond 2^38 (%g): not supported by the fp32 search", (double)box_pad * 1048576.0);
   TreeBuilder tb(*d, box_pad);
@@ -628,6 +683,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   Box root_box;
   if (!tb.resolve(d->root, 0, root_ref, root_box)) return sol_fail(SOL_EINVAL, "world: %s", tb.error.c_str());
   if (SOL_REF_KIND(root_ref) == SOL_REF_NONE) return sol_fail(SOL_EINVAL, "world is empty");
+  if (sol_dev_overrides().verbose) std::fprintf(stderr, "[solstrale] create: reference tree resolved at %.1f ms\n", 1e3 * seconds_since(t_begin));
   std::vector<DMedium> mediums(d->n_mediums);
   uint32_t medium_depth = 0;
   for (uint32_t i = 0; i < d->n_mediums; ++i) {
@@ -761,6 +817,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   std::string fallback_note;
   if (!device_build) { int rc0 = host_candidates(want); if (rc0) return rc0; }
   double t_host_trees = seconds_since(t_begin);
+  if (sol_dev_overrides().verbose) std::fprintf(stderr, "[solstrale] create: host part done at %.1f ms\n", 1e3 * t_host_trees);
 
   // ---- lights ----
   std::vector<uint32_t> lights(d->lights, d->lights + d->n_lights);
@@ -790,23 +847,52 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   if (device_build) {
     // The clustering radius of the device build decides little on average and a few per cent on any one scene, not monotonically (greedy
     // clustering; MI355X, 1080p x 64 spp, ms with radius 8 / 16 / 32 / 64: C3 61.0 / 63.0 / 63.8 / 65.0, C2 37.1 / 35.7 / 34.7 / 37.3, C5
-    // 37.7 / 38.0 / 37.6 / 36.8, heterogeneous atrium 67.8 / 68.2 / 74.7 / 76.2 - profiles/r04_tree_ploc_radius.txt): SOL_TREE_AUTO builds
-    // the tree with radius 8, 16 and 32 and lets the counted probe choose, as the host path does among its candidates (the probe's
-    // cost - 2.5 per node visit, 1 per primitive test - ranks them as the render times do). An explicit SOL_TREE_DEVICE builds one
-    // tree (radius 16) for the shortest creation time; SOL_PLOC_R forces a radius.
+    // 37.7 / 38.0 / 37.6 / 36.8, heterogeneous atrium 67.8 / 68.2 / 74.7 / 76.2 - profiles/r04_tree_ploc_radius.txt): round 4's SOL_TREE_AUTO
+    // built the tree with radius 16, 8 and 32, uploaded all three and let the counted probe choose (the probe's cost - 2.5 per node visit,
+    // 1 per primitive test - ranks them as the render times do): C5 paid twice the build time for a 0 % choice. An explicit
+    // SOL_TREE_DEVICE builds one tree (radius 16); SOL_PLOC_R forces a radius.
     const auto t_dev0 = std::chrono::steady_clock::now();
+    // Round 5: two radii (16 never won a probe on the four scene families and costs a third of the build time), each built as far as the
+    // collapse's surface-area cost of the whole tree; what is emitted, uploaded and probed follows from the two costs
+    // (profiles/r05_scene_creation.txt: on triangle meshes the cost ranks the candidates as the probes and the render times do - C3 1.7 %, the
+    // heterogeneous atrium 2.1 % apart -; on C5 the candidates are 0.3 % apart and render within 1 % of each other; on C2's spheres they are
+    // 0.6 % apart and the cost ranks them the WRONG way round - box area overstates how often a sphere is hit - by 7 % of render time):
+    //   apart by less than 0.4 % or by more than 1.2 %: the cheaper tree, unprobed;   in between: both, the counted probe decides.
     std::vector<int> radii = {16};
     if (ovr.ploc_radius > 0) radii = {ovr.ploc_radius};
-    else if (opt.world_tree == SOL_TREE_AUTO && ovr.bvh.empty()) radii = {16, 8, 32};
+    else if (opt.world_tree == SOL_TREE_AUTO && ovr.bvh.empty()) radii = {8, 32};
     const uint32_t counts[3] = {d->n_triangles, d->n_spheres, d->n_quads};
     std::vector<SolBuildPrim> build_prims;
     rc = collect_build_prims(tb.nodes, root_ref, root_box, build_prims);
+    const SolSplitOptions sopt = split_options(ovr, &opt);
+    std::vector<std::unique_ptr<DevicePrepared>> prepared;
+    std::vector<int> prepared_radius;
     for (int radius : radii) {
-      if (rc && cands.empty()) break;
+      if (rc && prepared.empty()) break;
+      std::unique_ptr<DevicePrepared> pr(new DevicePrepared);
+      rc = device_world_tree_prepare(build_prims, root_box, box_pad, counts, tris, sopt, radius, s->stream, *pr);
+      if (rc) {
+        if (!prepared.empty()) { rc = SOL_OK; continue; }  // (a later candidate failed: the earlier ones stand)
+        break;
+      }
+      if (ovr.verbose) std::fprintf(stderr, "[solstrale] device tree (radius %d): collapse cost %.6g\n", radius, (double)pr->dt.collapse_cost);
+      prepared.push_back(std::move(pr));
+      prepared_radius.push_back(radius);
+    }
+    if (prepared.size() == 2) {
+      const double a = prepared[0]->dt.collapse_cost, b = prepared[1]->dt.collapse_cost;
+      const double apart = (a > 0. && b > 0.) ? std::fabs(a - b) / std::min(a, b) : 0.;
+      const bool probe_both = ovr.probe_radii > 0 || (ovr.probe_radii < 0 && apart >= 0.004 && apart <= 0.012);  // (SOL_PROBE_RADII=1 / 0 forces)
+      if (b < a) { std::swap(prepared[0], prepared[1]); std::swap(prepared_radius[0], prepared_radius[1]); }  // the cheaper one first
+      if (ovr.verbose) std::fprintf(stderr, "[solstrale] device trees: collapse costs %.4f %% apart -> %s\n", apart * 100., probe_both ? "both emitted, the probe decides" : "the cheaper one, unprobed");
+      if (!probe_both) { prepared.pop_back(); prepared_radius.pop_back(); }
+    }
+    for (size_t k = 0; k < prepared.size() && !(rc && cands.empty()); ++k) {
+      const int radius = prepared_radius[k];
       TreeCand c;
       c.name = radii.size() > 1 ? "device" + std::to_string(radius) : "device";
       DeviceSplitInfo si;
-      rc = device_world_tree(build_prims, root_box, box_pad, counts, tris, split_options(ovr, &opt), radius, s->stream, c.lay, c.emin, &si);
+      rc = device_world_tree_finish(*prepared[k], counts, sopt, c.lay, c.emin, &si);
       if (ovr.verbose) std::fprintf(stderr, "[solstrale] device tree (radius %d): pre-splitting %u triangles into %u extra references, box area ratio %.3f%s; %u reinsertion moves\n",
                                     radius, si.split_triangles, si.extra_references, si.area_ratio, si.extra_references ? "" : " (not kept)", si.reinsertion_moves);
       if (!rc) {
@@ -818,7 +904,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
         break;
       }
       // Small scenes: the radii often give the SAME tree (the layout is a function of the tree alone, so equal trees are equal
-      // bytes) - a duplicate is not uploaded and probed a second time (the reference's test scene: three times 33 identical nodes).
+      // bytes) - a duplicate is not uploaded and probed a second time (the reference's test scene: 33 identical nodes either way).
       bool duplicate = false;
       for (const TreeCand& p : cands) {
         const WideLayout &a = p.lay, &b = c.lay;
@@ -833,6 +919,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
       cands.push_back(std::move(c));
       dev_info.push_back(si);
     }
+    prepared.clear();
     s->build_times[2] = seconds_since(t_dev0);
     if (!cands.empty()) {
       rc = SOL_OK;
@@ -924,7 +1011,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
   S.sphere_slack = box_pad * 0.5f;
   if ((rc = sol_upload(light_triangle_frames(*d), &s->light_tri))) return rc;
   S.light_tri = s->light_tri;
-  S.tri_delta = sol_scene_has_needles(d) ? box_pad * 0.8f : 0.0f;
+  S.tri_delta = scene_has_needles ? box_pad * 0.8f : 0.0f;
   s->strict_triangles = S.tri_delta > 0.0f;
   S.env = nullptr; S.env_w = S.env_h = 0; S.env_scale = 1.0f;
   if (has_env) {
@@ -1000,14 +1087,29 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     if ((rc = sol_set_partition(s, 0, 1)) || (rc = sol_clear(s))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
-  // Background blocks: constant background only (an environment map is looked up per ray)
-  if (!opt.no_background_blocks && ovr.background_blocks != 0 && !has_env) {
-    find_background_blocks(cands[chosen].lay, cands[chosen].emin, S.cam, d->width, d->height, 64.0 * (double)box_pad, s->background_block,
-                           s->n_background, s->background_pixels);
-    if (ovr.verbose) std::fprintf(stderr, "[solstrale] background blocks: %u of %u (%u pixels)\n", s->n_background, s->blocks_x * s->blocks_y, s->background_pixels);
-    if (s->n_background == 0) s->background_block.clear();
-    else if ((rc = sol_rebuild_order(s))) return rc;  // (also without the cost probe below)
+  // Background blocks: constant background only (an environment map is looked up per ray). The proof is host work (0.06 s for C5 at 1080p): it
+  // runs on a thread of its own beside the cost probe's render below and is adopted after it (the probe traces every block either way).
+  std::future<void> background_proof;
+  std::vector<uint8_t> bg_block;
+  uint32_t bg_n = 0, bg_pixels = 0;
+  const bool want_background = !opt.no_background_blocks && ovr.background_blocks != 0 && !has_env;
+  if (want_background) {
+    const WideLayout* lay_ptr = &cands[chosen].lay;
+    const uint32_t lay_emin = cands[chosen].emin;
+    const DCamera cam = S.cam;
+    const double inflate = 64.0 * (double)box_pad;
+    const uint32_t iw = d->width, ih = d->height;
+    background_proof = std::async(std::launch::async, [=, &bg_block, &bg_n, &bg_pixels]() { find_background_blocks(*lay_ptr, lay_emin, cam, iw, ih, inflate, bg_block, bg_n, bg_pixels); });
   }
+  auto adopt_background = [&]() -> int {  // (waits for the proof; idempotent)
+    if (!background_proof.valid()) return SOL_OK;
+    background_proof.get();
+    s->background_block = std::move(bg_block); s->n_background = bg_n; s->background_pixels = bg_pixels;
+    if (ovr.verbose) std::fprintf(stderr, "[solstrale] background blocks: %u of %u (%u pixels)\n", s->n_background, s->blocks_x * s->blocks_y, s->background_pixels);
+    if (s->n_background == 0) { s->background_block.clear(); return SOL_OK; }
+    return sol_rebuild_order(s);  // (also without the cost probe below)
+  };
+  struct ProofJoin { std::future<void>& f; ~ProofJoin() { if (f.valid()) f.wait(); } } proof_join{background_proof};  // (an early return must not leave the thread behind)
   // Cost probe: per 8x8 block, the ray count of the longest 4-sample item in a counted render of the whole frame, for the
   // heavy-first work order
   // (rebuild_order; sol_path.h decode_item_ordered). SOL_ORDER=0 switches it off.
@@ -1022,6 +1124,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     S.block_cost = cost_dev;
     S.block_work = work_dev;
     rc = e == hipSuccess ? sol_render_impl(s, 0, 4, 0xC057ull, true) : SOL_EDEVICE;
+    if (int rb = adopt_background()) { if (rc == SOL_OK) rc = rb; }
     S.block_cost = nullptr;
     S.block_work = nullptr;
     s->block_cost.assign(nb, 0u);
@@ -1048,6 +1151,7 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (ovr.verbose) std::fprintf(stderr, "[solstrale] work order: %u of %u blocks heavy (first)\n", S.n_first, s->n_local_blocks);
   }
+  if ((rc = adopt_background())) return rc;  // (no cost probe ran: the proof is adopted here)
   s->build_times[3] = seconds_since(t_probe0);
   cleanup.keep = true;
   *out = s;

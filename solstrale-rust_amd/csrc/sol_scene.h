@@ -59,6 +59,7 @@ struct SolDevOverrides {
   int switch_below = -1;         // SOL_SWITCH (-1: default)
   int max_bpc = -1;              // SOL_MAX_BPC
   int fine_tail = -2;            // SOL_FINE_TAIL (-2: not set)
+  int probe_radii = -1;          // SOL_PROBE_RADII (AUTO device build: 1 = emit and probe both clustering radii, 0 = never, -1 = by the collapse costs)
   int pool_swap_min = 0;         // SOL_POOL_SWAP (pool kernel: RenderParams::swap_min; 0: the default)
   int pool_slots = 0, wf_slots = 0, wf_min_items = -1;  // SOL_POOL_SLOTS / SOL_WF_SLOTS / SOL_WF_MIN_ITEMS (v2 / v3)
   std::string rccl_lib;          // SOL_RCCL_LIB: the communication library to dlopen instead of librccl.so.1 (tests)
