@@ -31,6 +31,7 @@ import glob
 import json
 import os
 import pickle
+import resource
 import shutil
 import socket
 import subprocess
@@ -576,6 +577,9 @@ def worker(args):
                          "samples_per_launch": int(launch_samples),
                          "counters_per_sample": {k: round(v / st["samples"], 4) for k, v in st_traced.items() if k not in ("samples", "max_stack")}},
             "setup_s": {"scene_and_bvh_build_host": round(t_build, 2), "sol_scene_create": round(t_upload, 2),
+                        "scene_source": ("OBJ + MTL file through the host loader (parse, material table, textures, reference BVH, flatten)" if args.obj else
+                                         "procedural stand-in generated in Python, reference BVH built by the C++ host"),
+                        "peak_host_rss_mb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1),
                         **{"create_" + k: round(v, 3) for k, v in bt.items()}},
             "world_tree": {"builder": tree_info["tree_name"], "presplit_extra_references": tree_info["split_references"],
                            "presplit_triangles": tree_info["split_triangles"], "presplit_box_area_ratio": round(tree_info["split_area_ratio"], 4),

@@ -40,11 +40,19 @@ struct ObjMesh {
   size_t material_id = 0;
 };
 
+// (a plain scan: through an istringstream the tokens of a 1.1 M-face file cost more than everything after them)
 std::vector<std::string> split_ws(const std::string& s) {
   std::vector<std::string> out;
-  std::istringstream is(s);
-  std::string t;
-  while (is >> t) out.push_back(t);
+  const char* p = s.data();
+  const char* const end = p + s.size();
+  auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; };
+  while (p < end) {
+    while (p < end && is_ws(*p)) ++p;
+    const char* q = p;
+    while (q < end && !is_ws(*q)) ++q;
+    if (q > p) out.emplace_back(p, (size_t)(q - p));
+    p = q;
+  }
   return out;
 }
 

@@ -285,20 +285,51 @@ def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1
     rc = render_config or RenderConfig(width=1920, height=1080, samples_per_pixel=512)
     b = SceneBuilder()
     mats = []
+    for kind, value in atrium_materials(n_materials, texture_size):
+        mats.append(b.Lambertian(b.ImageMap(value)) if kind == "image" else b.Lambertian(b.SolidColor(*value)))
+    tri, slots, uv = atrium_mesh(n_triangles, n_materials, mesh)
+    first, n = b.triangles(tri, np.asarray(mats, dtype=np.int32)[slots], uv)
+    model = b.Bvh_range(first, n)  # like Obj::load -> Bvh::new(triangles) (src/loader/obj.rs:135)
+    Hh = ATRIUM_HEIGHT
+    light = b.Quad((-6., Hh + 1.5, -2.0), (12., 0, 0), (0, 0, 4.0), b.DiffuseLight(18., 17., 15.))
+    world = b.Bvh([model, light])
+    if camera == "interior":
+        cam = CameraConfig(vertical_fov_degrees=60., aperture_size=0., look_from=(-14.2, 1.7, -5.0), look_at=(13.0, 2.3, -4.9), up=(0, 1, 0))
+    elif camera == "default":
+        cam = CameraConfig(vertical_fov_degrees=55., aperture_size=0., look_from=(-13.0, 2.2, 0.6), look_at=(6.0, 4.5, -0.4),
+                           up=(0, 1, 0))
+    elif camera == "far":  # a long lens 190 units above the hall, looking down through the roof opening past the light: floor, galleries, drapes
+        cam = CameraConfig(vertical_fov_degrees=7.5, aperture_size=0., look_from=(47.0, 181.0, 34.0), look_at=(0.0, 3.0, 0.0), up=(0, 1, 0))
+    else:
+        raise ValueError(f"unknown camera preset {camera!r}")
+    return b.finish(world, cam, (0.35, 0.5, 0.75), rc)
+
+
+ATRIUM_HEIGHT = 12.0
+
+
+def atrium_materials(n_materials=24, texture_size=1024):
+    """The atrium's material table: ("image", (H, W, 3) uint8) for the first 8 slots - procedural textures -, ("solid", rgb) for the rest.
+    (tests/tools/export_obj.py writes the same table as an MTL file with the textures beside it.)"""
+    out = []
     for i in range(n_materials):
         if i < 8:
-            mats.append(b.Lambertian(b.ImageMap(_procedural_texture(i % 3, texture_size, 100 + i))))
+            out.append(("image", _procedural_texture(i % 3, texture_size, 100 + i)))
         else:
-            c = 0.25 + 0.6 * counter_uniform(77, 3, i)
-            mats.append(b.Lambertian(b.SolidColor(*c)))
-    L, Wd, Hh = 15.0, 6.0, 12.0  # half length (x), half width (z), height (y)
+            out.append(("solid", tuple(float(x) for x in 0.25 + 0.6 * counter_uniform(77, 3, i))))
+    return out
+
+
+def atrium_mesh(n_triangles=SPONZA_TRIANGLES, n_materials=24, mesh="regular"):
+    """The atrium's triangles: (N, 3, 3) vertices, (N,) material SLOTS (indices into atrium_materials), (N, 3, 2) float32 texture coordinates."""
+    L, Wd, Hh = 15.0, 6.0, ATRIUM_HEIGHT  # half length (x), half width (z), height (y)
     parts = []  # (weight, surface, material index, uv tiling)
     tris, uvs, mids = [], [], []
     made = 0
     if mesh == "heterogeneous":
         for f, nu, nv, m, tile in _heterogeneous_atrium_parts(L, Wd, Hh):
             t, uv = _grid(f, nu, nv, tile)
-            tris.append(t), uvs.append(uv), mids.append(np.full(len(t), mats[m % n_materials], dtype=np.int32))
+            tris.append(t), uvs.append(uv), mids.append(np.full(len(t), m % n_materials, dtype=np.int32))
             made += len(t)
     elif mesh != "regular":
         raise ValueError(f"unknown mesh preset {mesh!r}")
@@ -356,7 +387,7 @@ def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1
             nu = max(1, int(round(math.sqrt(cells * 2.0))))
             nv = max(1, cells // nu)
             t, uv = _grid(f, nu, nv, tile)
-            tris.append(t), uvs.append(uv), mids.append(np.full(len(t), mats[m % n_materials], dtype=np.int32))
+            tris.append(t), uvs.append(uv), mids.append(np.full(len(t), m % n_materials, dtype=np.int32))
             made += len(t)
     # filler: a strip of small pennants along the -z gallery rail until the exact count is reached
     missing = n_triangles - made
@@ -371,23 +402,10 @@ def sponza_like(render_config=None, n_triangles=SPONZA_TRIANGLES, texture_size=1
         p2 = np.stack([x, np.full_like(x, 6.2), np.full_like(x, -Wd + 2.05)], 1)
         tris.append(np.stack([p0, p1, p2], 1))
         uvs.append(np.tile(np.array([[0, 0], [1, 0], [.5, 1]], np.float32), (missing, 1, 1)))
-        mids.append(np.full(missing, mats[(n_materials - 1)], dtype=np.int32))
+        mids.append(np.full(missing, n_materials - 1, dtype=np.int32))
     tri = np.concatenate(tris)
     assert len(tri) == n_triangles, (len(tri), n_triangles)
-    first, n = b.triangles(tri, np.concatenate(mids), np.concatenate(uvs))
-    model = b.Bvh_range(first, n)  # like Obj::load -> Bvh::new(triangles) (src/loader/obj.rs:135)
-    light = b.Quad((-6., Hh + 1.5, -2.0), (12., 0, 0), (0, 0, 4.0), b.DiffuseLight(18., 17., 15.))
-    world = b.Bvh([model, light])
-    if camera == "interior":
-        cam = CameraConfig(vertical_fov_degrees=60., aperture_size=0., look_from=(-14.2, 1.7, -5.0), look_at=(13.0, 2.3, -4.9), up=(0, 1, 0))
-    elif camera == "default":
-        cam = CameraConfig(vertical_fov_degrees=55., aperture_size=0., look_from=(-13.0, 2.2, 0.6), look_at=(6.0, 4.5, -0.4),
-                           up=(0, 1, 0))
-    elif camera == "far":  # a long lens 190 units above the hall, looking down through the roof opening past the light: floor, galleries, drapes
-        cam = CameraConfig(vertical_fov_degrees=7.5, aperture_size=0., look_from=(47.0, 181.0, 34.0), look_at=(0.0, 3.0, 0.0), up=(0, 1, 0))
-    else:
-        raise ValueError(f"unknown camera preset {camera!r}")
-    return b.finish(world, cam, (0.35, 0.5, 0.75), rc)
+    return tri, np.concatenate(mids), np.concatenate(uvs)
 
 
 def obj_bounds(path):
@@ -413,10 +431,11 @@ def obj_file_scene(path, render_config=None, camera=None, light=None, background
     and a Quad light over the middle third of the model's top (y up), as in the atrium stand-in."""
     rc = render_config or RenderConfig(width=1920, height=1080, samples_per_pixel=512)
     d, fn = os.path.split(os.path.abspath(path))
-    lo, hi = obj_bounds(path)
-    ext = hi - lo
-    ax = 0 if ext[0] >= ext[2] else 2  # long horizontal axis
-    ox = 2 - ax
+    if light is None or camera is None:  # (a scan of the file's vertices in Python: seconds on a million-face file, so only when a default is asked for)
+        lo, hi = obj_bounds(path)
+        ext = hi - lo
+        ax = 0 if ext[0] >= ext[2] else 2  # long horizontal axis
+        ox = 2 - ax
     b = SceneBuilder()
     model = b.load_obj(d + os.sep, fn, None, b.Lambertian(b.SolidColor(0.7, 0.7, 0.7)))
     if light is None:
@@ -476,6 +495,31 @@ def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES, environment=Fa
     glass = b.Dielectric(b.SolidColor(1., 1., 1.), None, 1.5)
     stone = b.Lambertian(b.SolidColor(.55, .52, .5))
     cloth = b.Lambertian(b.SolidColor(.6, .15, .12))
+    tri, slots, uv = statue_mesh(n_triangles)
+    first, n = b.triangles(tri, np.asarray([metal, glass, stone, cloth], dtype=np.int32)[slots], uv)
+    model = b.Bvh_range(first, n)
+    orb = b.Sphere((2.2, 0.7, 1.2), 0.7, glass)
+    floor = b.Quad((-12., 0., -12.), (24., 0, 0), (0, 0, 24.), b.Lambertian(b.SolidColor(.4, .42, .45)))
+    light = b.Quad((-2.5, 8.5, -1.0), (5., 0, 0), (0, 0, 4.), b.DiffuseLight(20., 19., 17.))
+    if camera == "closeup":  # STRESS variant: the statue fills the frame, seen from above so that the glass head lies in front of the metal body
+        cam = CameraConfig(vertical_fov_degrees=40., aperture_size=0., look_from=(1.6, 7.2, 3.4), look_at=(0.0, 3.1, 0.0), up=(0, 1, 0))
+    elif camera == "default":
+        cam = CameraConfig(vertical_fov_degrees=38., aperture_size=0., look_from=(4.5, 3.6, 8.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
+    elif camera == "far":  # the default view from ten times the distance through a lens ten times as long (the regime in which fp32 loses a distant origin's digits)
+        cam = CameraConfig(vertical_fov_degrees=3.94, aperture_size=0., look_from=(43.2, 12.6, 80.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
+    else:
+        raise ValueError(f"unknown camera preset {camera!r}")
+    if environment:  # EXTENSION (not in the reference): the "HDRI env light" of BASELINE.json's config 5, as a procedural HDR sky
+        b.environment(procedural_sky(), 1.0)
+    return b.finish(b.Bvh([model, orb, floor, light]), cam, (0.25, 0.3, 0.4), rc)
+
+
+STATUE_MATERIALS = (("metal body", (.85, .7, .45)), ("glass head", (1., 1., 1.)), ("stone plinth", (.55, .52, .5)), ("cloth drape", (.6, .15, .12)))
+
+
+def statue_mesh(n_triangles=STATUE_TRIANGLES):
+    """The statue's triangles: (N, 3, 3) vertices, (N,) material slots (0 metal body, 1 glass head, 2 stone plinth, 3 cloth drape), (N, 3, 2) texture coordinates."""
+    metal, glass, stone, cloth = 0, 1, 2, 3
 
     def noise(u, v, k, amp):  # smooth, periodic in u
         return amp * (np.sin(2 * np.pi * (k * u) + 7.0 * v) * np.cos(2 * np.pi * (0.5 * k * v) + 3.0 * u) +
@@ -512,22 +556,7 @@ def statue_like(render_config=None, n_triangles=STATUE_TRIANGLES, environment=Fa
         t, uv = _grid(f, nu, nv)
         tris.append(t), uvs.append(uv), mids.append(np.full(len(t), m, dtype=np.int32))
         made += len(t)
-    first, n = b.triangles(np.concatenate(tris), np.concatenate(mids), np.concatenate(uvs))
-    model = b.Bvh_range(first, n)
-    orb = b.Sphere((2.2, 0.7, 1.2), 0.7, glass)
-    floor = b.Quad((-12., 0., -12.), (24., 0, 0), (0, 0, 24.), b.Lambertian(b.SolidColor(.4, .42, .45)))
-    light = b.Quad((-2.5, 8.5, -1.0), (5., 0, 0), (0, 0, 4.), b.DiffuseLight(20., 19., 17.))
-    if camera == "closeup":  # STRESS variant: the statue fills the frame, seen from above so that the glass head lies in front of the metal body
-        cam = CameraConfig(vertical_fov_degrees=40., aperture_size=0., look_from=(1.6, 7.2, 3.4), look_at=(0.0, 3.1, 0.0), up=(0, 1, 0))
-    elif camera == "default":
-        cam = CameraConfig(vertical_fov_degrees=38., aperture_size=0., look_from=(4.5, 3.6, 8.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
-    elif camera == "far":  # the default view from ten times the distance through a lens ten times as long (the regime in which fp32 loses a distant origin's digits)
-        cam = CameraConfig(vertical_fov_degrees=3.94, aperture_size=0., look_from=(43.2, 12.6, 80.0), look_at=(0.2, 2.6, 0.0), up=(0, 1, 0))
-    else:
-        raise ValueError(f"unknown camera preset {camera!r}")
-    if environment:  # EXTENSION (not in the reference): the "HDRI env light" of BASELINE.json's config 5, as a procedural HDR sky
-        b.environment(procedural_sky(), 1.0)
-    return b.finish(b.Bvh([model, orb, floor, light]), cam, (0.25, 0.3, 0.4), rc)
+    return np.concatenate(tris), np.concatenate(mids), np.concatenate(uvs)
 
 
 # ---------------------------------------------------------------------------------------------------------------
