@@ -265,14 +265,19 @@ __global__ void __launch_bounds__(BT) k_split_sum(const float* __restrict__ prio
 // pass 1: how many parts each primitive becomes (1: not split); pass 2 (out != nullptr): the parts
 __global__ void __launch_bounds__(BT) k_split(const SolBuildPrim* __restrict__ p, uint32_t n, const DTri* __restrict__ tris, uint32_t n_tris, SplitGrid G,
                                                const float* __restrict__ prio, float D, uint32_t* __restrict__ parts, const uint32_t* __restrict__ offset,
-                                               SolBuildPrim* __restrict__ out, uint32_t* __restrict__ extra_of, uint32_t* __restrict__ n_split, double* __restrict__ areas) {
+                                               SolBuildPrim* __restrict__ out, uint32_t* __restrict__ extra_of, uint32_t* __restrict__ n_split,
+                                               unsigned long long* __restrict__ areas, double area_scale) {
+  // areas[0] / [1]: summed box area of the primitives before / after splitting, in FIXED POINT (area x area_scale, 2^40 per root-box area): integer
+  // atomics add up to the same total in any order, so whether the splits are kept (the 0.85 threshold) is the same decision in every run and on
+  // every rank (round-4 advisor: double atomics rounded order-dependently; near the threshold two ranks of a job could keep different trees)
+  auto fixed = [&](float a) { return (unsigned long long)((double)a * area_scale); };
   const uint32_t i = blockIdx.x * BT + threadIdx.x;
   if (i >= n) return;
   const SolBuildPrim me = p[i];
   const int s = (int)fminf((float)SPLIT_CAP, floorf(D * prio[i]));
   const float a_me = box_area(me.box);
   if (s <= 0) {
-    if (out) out[i] = me; else { parts[i] = 0u; if (a_me > 0.f && a_me < 1e30f) { atomicAdd(&areas[0], (double)a_me); atomicAdd(&areas[1], (double)a_me); } }
+    if (out) out[i] = me; else { parts[i] = 0u; if (a_me > 0.f && a_me < 1e30f) { atomicAdd(&areas[0], fixed(a_me)); atomicAdd(&areas[1], fixed(a_me)); } }
     return;
   }
   const uint32_t tri = SOL_REF_INDEX(me.ref);
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(BT) k_split(const SolBuildPrim* __restrict__ p
   if (!out) {
     parts[i] = k - 1u;
     if (k > 1u) atomicAdd(n_split, 1u);
-    if (a_me > 0.f && a_me < 1e30f) { atomicAdd(&areas[0], (double)a_me); atomicAdd(&areas[1], (double)a_parts); }
+    if (a_me > 0.f && a_me < 1e30f) { atomicAdd(&areas[0], fixed(a_me)); atomicAdd(&areas[1], fixed(fminf(a_parts, a_me * 64.f))); }
   }
 }
 
@@ -600,13 +605,21 @@ __global__ void __launch_bounds__(BT) k_area_sum(uint32_t n_nodes, uint32_t n_le
 }
 
 // After the reinsertion rounds: every inner node's children name it as their parent, are two different nodes, and its box is the
-// union of theirs; the root has no parent. [0] broken links, [1] wrong boxes.
+// union of theirs; the root has no parent; every leaf reaches the root. [0] broken links, [1] wrong boxes, [2] leaves cut off from the root.
 __global__ void __launch_bounds__(BT) k_validate(uint32_t n_nodes, uint32_t n_leaves, uint32_t root, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ left,
                                                   const uint32_t* __restrict__ right, const float* __restrict__ nbox, uint32_t* __restrict__ bad) {
   const uint32_t m = blockIdx.x * BT + threadIdx.x;
   if (m >= n_nodes) return;
   if ((m == root) != (parent[m] == NONE)) atomicAdd(&bad[0], 1u);
-  if (m < n_leaves) return;
+  if (m < n_leaves) {
+    // every leaf reaches the root: moves that tied a sub-tree into a ring pass the local checks below (each node of the ring has a parent
+    // that lists it) and would surface later as a bad permutation, with a misleading message (round-4 advisor)
+    uint32_t a = m;
+    int steps = 0;
+    while (parent[a] != NONE && ++steps < 8192) a = parent[a];
+    if (a != root) atomicAdd(&bad[2], 1u);
+    return;
+  }
   const uint32_t l = left[m], r = right[m];
   if (l >= n_nodes || r >= n_nodes || l == r || parent[l] != m || parent[r] != m) { atomicAdd(&bad[0], 1u); return; }
   for (int k = 0; k < 6; k += 2) {
@@ -944,6 +957,10 @@ bool sol_build_world_tree_prepare(const SolBuildPrim* prims, uint32_t n_in, cons
     SplitGrid G;
     for (int a = 0; a < 3; ++a) { G.lo[a] = root_box[2 * a]; G.inv_cell[a] = inv[a]; G.cell[a] = ext[a] > 0.f && ext[a] < 1e30f ? ext[a] / 2097152.0f : 0.f; }
     G.pad = pad;
+    // fixed-point scale of the area sums: 2^40 per root-box area (a primitive's box lies inside the root box: every term below 2^40 and the sum of
+    // up to 2^23 of them below 2^63)
+    const double root_area = (double)ext[0] * ext[1] + (double)ext[1] * ext[2] + (double)ext[2] * ext[0];
+    const double area_scale = root_area > 0. && root_area < 1e60 ? 1099511627776.0 / root_area : 0.;
     int log2n = 0;
     while ((2u << log2n) <= n_in) ++log2n;  // floor(log2 n)
     G.level_max = std::max(0, std::min(3 * GRID_BITS, log2n - split.level_slack));
@@ -952,7 +969,7 @@ bool sol_build_world_tree_prepare(const SolBuildPrim* prims, uint32_t n_in, cons
     float* prio;
     uint32_t *parts, *poff, *n_split;
     unsigned long long* total;
-    double* areas;
+    unsigned long long* areas;
     B_TRY(S.get(&d_tris, counts_in[0])); B_TRY(S.get(&prio, n_in)); B_TRY(S.get(&parts, n_in)); B_TRY(S.get(&poff, n_in)); B_TRY(S.get(&n_split, 1)); B_TRY(S.get(&total, 1));
     B_TRY(S.get(&areas, 2));
     B_TRY(hipMemcpyAsync(d_tris, tris, (size_t)counts_in[0] * sizeof(DTri), hipMemcpyHostToDevice, stream));
@@ -997,7 +1014,7 @@ bool sol_build_world_tree_prepare(const SolBuildPrim* prims, uint32_t n_in, cons
       B_TRY(hipMemsetAsync(n_split, 0, 4, stream));
       B_TRY(hipMemsetAsync(areas, 0, 16, stream));
       hipLaunchKernelGGL(k_split, dim3(nb_in), dim3(BT), 0, stream, d_prims, n_in, d_tris, counts_in[0], G, prio, D, parts, (const uint32_t*)nullptr, (SolBuildPrim*)nullptr,
-                         (uint32_t*)nullptr, n_split, areas);
+                         (uint32_t*)nullptr, n_split, areas, area_scale);
       B_LAUNCHED(k_split);
       size_t sb = 0;
       B_TRY(rocprim::exclusive_scan(nullptr, sb, parts, poff, 0u, (size_t)n_in, rocprim::plus<uint32_t>(), stream));
@@ -1008,18 +1025,18 @@ bool sol_build_world_tree_prepare(const SolBuildPrim* prims, uint32_t n_in, cons
       B_TRY(hipMemcpyAsync(&last[0], poff + (n_in - 1), 4, hipMemcpyDeviceToHost, stream));
       B_TRY(hipMemcpyAsync(&last[1], parts + (n_in - 1), 4, hipMemcpyDeviceToHost, stream));
       B_TRY(hipMemcpyAsync(&out.split_triangles, n_split, 4, hipMemcpyDeviceToHost, stream));
-      double h_areas[2] = {0., 0.};
+      unsigned long long h_areas[2] = {0ull, 0ull};
       B_TRY(hipMemcpyAsync(h_areas, areas, 16, hipMemcpyDeviceToHost, stream));
       B_TRY(hipStreamSynchronize(stream));
       const uint32_t extra = last[0] + last[1];
-      out.split_area_ratio = h_areas[0] > 0. ? (float)(h_areas[1] / h_areas[0]) : 1.f;
+      out.split_area_ratio = h_areas[0] > 0ull ? (float)((double)h_areas[1] / (double)h_areas[0]) : 1.f;
       const bool keep = out.split_area_ratio <= split.max_area_ratio;
       if (!keep) out.split_triangles = 0;
       if (keep && extra > 0 && (uint64_t)n_in + extra <= (SOL_WIDE_MAX_INDEX >> 1)) {
         SolBuildPrim* d_prims2;
         uint32_t* d_extra_of;
         B_TRY(S.get(&d_prims2, n_in + extra)); B_TRY(S.get(&d_extra_of, extra));
-        hipLaunchKernelGGL(k_split, dim3(nb_in), dim3(BT), 0, stream, d_prims, n_in, d_tris, counts_in[0], G, prio, D, parts, (const uint32_t*)poff, d_prims2, d_extra_of, n_split, areas);
+        hipLaunchKernelGGL(k_split, dim3(nb_in), dim3(BT), 0, stream, d_prims, n_in, d_tris, counts_in[0], G, prio, D, parts, (const uint32_t*)poff, d_prims2, d_extra_of, n_split, areas, area_scale);
         B_LAUNCHED(k_split);
         out.extra_of.resize(extra);
         B_TRY(hipMemcpyAsync(out.extra_of.data(), d_extra_of, (size_t)extra * 4, hipMemcpyDeviceToHost, stream));
@@ -1159,14 +1176,17 @@ bool sol_build_world_tree_prepare(const SolBuildPrim* prims, uint32_t n_in, cons
     B_TRY(hipMemsetAsync(arrived, 0, (size_t)n_nodes * 4, stream));  // (k_collapse_cost counts arrivals again)
     B_TRY(hipMemsetAsync(n_moved, 0, 4, stream));
     uint32_t* bad;
-    B_TRY(S.get(&bad, 2));
-    B_TRY(hipMemsetAsync(bad, 0, 8, stream));
+    B_TRY(S.get(&bad, 3));
+    B_TRY(hipMemsetAsync(bad, 0, 12, stream));
     hipLaunchKernelGGL(k_validate, dim3(gn), dim3(BT), 0, stream, n_nodes, n, root_node, parent, left, right, nbox, bad);
     B_LAUNCHED(k_validate);
-    uint32_t h_bad[2] = {0, 0};
-    B_TRY(hipMemcpyAsync(h_bad, bad, 8, hipMemcpyDeviceToHost, stream));
+    uint32_t h_bad[3] = {0, 0, 0};
+    B_TRY(hipMemcpyAsync(h_bad, bad, 12, hipMemcpyDeviceToHost, stream));
     B_TRY(hipStreamSynchronize(stream));
-    if (h_bad[0] || h_bad[1]) { err = "device tree build: reinsertion left " + std::to_string(h_bad[0]) + " broken links and " + std::to_string(h_bad[1]) + " wrong boxes"; return false; }
+    if (h_bad[0] || h_bad[1] || h_bad[2]) {
+      err = "device tree build: reinsertion left " + std::to_string(h_bad[0]) + " broken links, " + std::to_string(h_bad[1]) + " wrong boxes and " + std::to_string(h_bad[2]) + " leaves that do not reach the root";
+      return false;
+    }
   }
   dbg("reinsertion done");
   // ---- 3. collapse costs ----
