@@ -477,6 +477,7 @@ def worker(args):
     # what a scaling curve needs to explain itself: every rank's kernel time, and the gather timed on its own (one more, untimed,
     # gather of the accumulators the last step left: host clock around sol_gather + synchronise, maximum over the ranks)
     per_rank_kernel_ms = coord.all(round(k_ms, 3))
+    per_rank_setup_s = coord.all((round(t_build, 3), round(t_upload, 3)))  # (every rank builds and creates its own copy of the scene)
     gather_ms = None
     if world > 1:
         fence()
@@ -591,6 +592,9 @@ def worker(args):
         if world > 1:
             out["rccl_ranks"] = rccl_ranks
             out["per_rank_kernel_ms"] = per_rank_kernel_ms
+            out["per_rank_setup_s"] = {"scene_and_bvh_build_host": [a for a, _ in per_rank_setup_s], "sol_scene_create": [b for _, b in per_rank_setup_s],
+                                       "note": "every rank loads / generates the scene and calls sol_scene_create itself (deterministic: same tree, same partition - checked); "
+                                               "outside the timed region, as the metric defines (SURVEY.md 8d)"}
             out["gather_ms"] = gather_ms
             out["gather_note"] = "one extra sol_gather (grouped ncclSend / ncclRecv into rank 0 + un-permute) after the timed region, host clock incl. the barrier; the timed steps contain their own"
             out["partition"] = {"table": bool(part["partition_table"]), "crc": part["partition_crc"], "agreed_by_all_ranks": True}

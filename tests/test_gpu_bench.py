@@ -66,6 +66,7 @@ def test_both_figures_in_a_multi_rank_line():
     d = _line(r.stdout)
     bb = d["background_blocks"]
     assert d["n_gpus"] == 2 and bb["blocks"] > 0 and bb["value_with_every_sample_traced"] > 0 and bb["value_with_every_sample_traced_steps"] == 2
+    assert len(d["per_rank_setup_s"]["sol_scene_create"]) == 2 and all(t > 0 for t in d["per_rank_setup_s"]["sol_scene_create"])
     assert d["rehearsal_frame_check"] is True
 
 
