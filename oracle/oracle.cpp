@@ -412,6 +412,13 @@ template <typename R> struct Tracer {
     if (!(u >= 0.f && u <= 1.f) || !(v >= 0.f && v <= 1.f)) return false;
     bool front = r.direction.dot(Q.normal) < (R)0;
     V3<R> normal = front ? Q.normal : Q.normal.neg();
+    // fp32 contract (seventh rule; the fifth rule's twin for a plane): the hit POINT of a quad is put back on the quad's plane. In single
+    // precision `origin + t * direction` from a distant origin - the Cornell box's camera, 800 units away with |d| = 800: a sum of magnitude 1000 that ends near
+    // 250 - lands up to ~1e-4 beside the plane, inside the box as often as outside; a scattered ray that leaves at a grazing angle from a point INSIDE re-hits the
+    // same quad from behind at t > 0.001 and the path goes dark (C1: 4 samples in 10^5, a frame 6e-5 darker than f64, every difference of one sign; found by the
+    // device-against-f64 gate of round 5). n . x = d is the quad's own plane (quad.rs:40-45), n a unit vector: one dot product and three FMAs put the point on it.
+    // u, v, t and the normal stay as computed. f64: nothing changes.
+    if (sizeof(R) == 4) hp = hp + Q.normal * (Q.d - Q.normal.dot(hp));
     out = {t, hp, {Q.u.unit(), Q.v.unit(), normal}, {u, v}, front, Q.mat};
     return true;
   }

@@ -60,6 +60,9 @@ DEV void build_surface(const DevScene& S, f3 o, f3 d, const Hit& h, const Rng& r
   } else if (kind == SOL_REF_QUAD) {  // quad.rs:175-193
     const DQuad Q = ldg_rec(S.quads + idx);
     f3 n = mk3(Q.nx, Q.ny, Q.nz);
+    // fp32 contract, seventh rule (oracle.cpp hit_quad): the hit point goes back onto the quad's plane n . x = d - `o + t d` from a distant origin lands
+    // ~1e-4 beside it, and a grazing ray scattered from a point behind the plane re-hits the same quad
+    sf.p = sf.p + n * (Q.d - dot3(n, sf.p));
     sf.front = dot3(d, n) < 0.0f;
     if (!sf.front) n = neg3(n);
     sf.onb = Onb{unit3(mk3(Q.ux, Q.uy, Q.uz)), unit3(mk3(Q.vx, Q.vy, Q.vz)), n};

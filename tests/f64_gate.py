@@ -29,6 +29,8 @@ from solstrale_amd import RenderConfig, scenes
 SPP = 64
 # (name, factory(render_config), width, height, [(crop name, rect), ...])
 CASES = [
+    ("c1_cornell", lambda rc: scenes.cornell_box(rc), 400, 400,
+     [("tall_box_and_wall", (60, 120, 188, 248)), ("light_and_ceiling", (136, 0, 264, 128))]),
     ("c2_cornell_spheres", lambda rc: scenes.cornell_spheres(rc), 1920, 1080,
      [("dense", (900, 500, 1028, 628)), ("box_edges", (1180, 560, 1308, 688))]),
     ("c3_atrium", lambda rc: scenes.sponza_like(rc), 1920, 1080,

@@ -139,6 +139,27 @@ def test_a_negative_radius_is_its_positive_twin():
     assert (np.abs(a - b).max(axis=-1) > 1e-3 * spp).mean() < 0.02
 
 
+def test_quad_hit_points_lie_on_the_plane():
+    """Seventh fp32-only rule, found by the device-against-f64 gate of round 5 on BASELINE config 1: the Cornell box's camera is 800 units from its quads with
+    |d| = 800, so `o + t d` lands ~1e-4 beside the plane in single precision; a grazing scattered ray that starts BEHIND the plane re-hits the same quad at
+    t > 0.001 and the path goes dark - 4 samples in 10^5, every difference of one sign (the crop below: z = -4.4 before the rule). With the point put back on the
+    plane n . x = d, float follows double."""
+    from solstrale_amd import scenes
+    spp = 64
+    sc = scenes.cornell_box(RenderConfig(400, 400, spp))
+    rect = (60, 120, 188, 248)  # the tall box and the wall behind it
+    a, sa = orc.render(sc, 0, spp, pu.SEED, real=orc.ORC_F32, rect=rect)
+    b, sb = orc.render(sc, 0, spp, pu.SEED, real=orc.ORC_F64, rect=rect)
+    a, b = a[rect[1]:rect[3], rect[0]:rect[2]], b[rect[1]:rect[3], rect[0]:rect[2]]
+    d = (a - b).sum(axis=-1)
+    z = d.sum() / np.sqrt((d ** 2).sum())
+    apart = (np.abs(a - b) > spp * (1e-4 + 1e-3 * np.abs(b) / spp)).any(axis=-1).mean()
+    assert abs(z) < 3.0, z                     # (was -4.43)
+    assert apart < 1.5e-3, apart               # (was 2.7e-3: the pixels that held a self-hit)
+    assert abs(a.mean() - b.mean()) < 2e-5 * b.mean(), (a.mean(), b.mean())  # (was -6.1e-5)
+    assert abs(sa["live_rays"] - sb["live_rays"]) < 2e-5 * sb["live_rays"]
+
+
 def test_spheres_through_a_long_lens():
     """Sixth fp32-only rule: the sphere test takes its discriminant from the distance of the centre to the ray and its roots without
     cancellation. With the reference's formula in single precision the random scenes seen from 100 times the distance (objects of size 1

@@ -1,6 +1,6 @@
 """The standing gate that is NOT common-mode: the HIP fp32 frame next to the oracle's DOUBLE instantiation - the reference's own arithmetic
 (src/hittable/sphere.rs:64-108, triangle.rs:119-173, quad.rs:150-194, geo/mod.rs:159-188; pinned by the reference's 22 golden images) -
-on two 128x128 crops of every BASELINE workload at its full scene and resolution: C2, C3, the heterogeneous stress mesh (both cameras),
+on two 128x128 crops of every BASELINE workload at its full scene and resolution: C1, C2, C3, the heterogeneous stress mesh (both cameras),
 C4 at 4K, C5, C5 + HDRI, the reference's profiling workload, and far-camera variants of C3 and C5 (the regime that hid the fp32 sphere
 defect of rounds 1-3: BASELINE config 2 rendered 8.3 % darker than f64 while every fp32-vs-fp32 parity test was green).
 
@@ -25,6 +25,7 @@ Z_MAX = 4.5
 # case -> (rel_of_noise, ceiling of `apart`). Measured |rel| / noise is at most 0.33 (c5_statue_far, glass rim) and 0.14 elsewhere;
 # `apart` at 64 spp: C2 0.27 (12 rays per sample through 10 000 spheres seen from 800 units), atrium 0.02 - 0.07, statue 0.002 - 0.044.
 BOUNDS = {
+    "c1_cornell": (0.6, 0.02),
     "c2_cornell_spheres": (0.6, 0.40),
     "c3_atrium": (0.6, 0.08),
     "c3_heterogeneous": (0.6, 0.08),
