@@ -510,6 +510,7 @@ int sol_world_tree_check(const SolSceneDesc* d, int use_sah, SolTreeCheck* out) 
 int sol_background_blocks(const SolSceneDesc* d, int use_sah, uint8_t* flags, size_t n_flags, uint32_t* n_found) {
   if (!d || !n_found || use_sah < 0) return sol_fail(SOL_EINVAL, "bad argument");
   *n_found = 0;
+  if (d->width < 2 || d->height < 2 || (uint64_t)d->width * d->height > 0x3FFFFFFFull) return sol_fail(SOL_EINVAL, "bad image size %ux%u", d->width, d->height);
   const uint32_t nb = ((d->width + SOL_TILE - 1) / SOL_TILE) * ((d->height + SOL_TILE - 1) / SOL_TILE);
   if (flags && n_flags < nb) return sol_fail(SOL_EINVAL, "%zu flags for %u blocks", n_flags, nb);
   const SolDevOverrides ovr = sol_dev_overrides();
@@ -575,7 +576,9 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     std::memset(&o, 0, sizeof o);
     o.kind = t.kind;
     if (t.kind == SOL_TEX_IMAGE) {
-      if (!t.width || !t.height || t.texel_offset + (uint64_t)t.width * t.height * 3 > d->n_texel_bytes)
+      // (no sum or product here may wrap: an offset of 2^64 - 1 plus a size is a small number again)
+      const uint64_t px = (uint64_t)t.width * t.height;
+      if (!t.width || !t.height || px > d->n_texel_bytes / 3 || t.texel_offset > d->n_texel_bytes - px * 3)
         return sol_fail(SOL_EINVAL, "texture %u: image outside texel buffer", i);
       o.w = t.width; o.h = t.height; o.offset = (uint32_t)t.texel_offset;
     } else if (t.kind == SOL_TEX_SOLID) {

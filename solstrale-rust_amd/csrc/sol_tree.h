@@ -396,10 +396,10 @@ struct WideBuilder {
         float cl = c[i].box.v[2 * a] - 2.0f * pad, chh = c[i].box.v[2 * a + 1] + 2.0f * pad;
         if (!std::isfinite(cl)) cl = lo[a];
         if (!std::isfinite(chh)) chh = hi[a];
-        long ql = (long)std::floor((cl - lo[a]) / scale[a]);
-        long qh = (long)std::ceil((chh - lo[a]) / scale[a]);
-        ql = std::min(255L, std::max(0L, ql));
-        qh = std::min(255L, std::max(0L, qh));
+        // (clamped as floats: outside a refused range - range_error above - the quotient can be infinite or NaN, which no integer holds)
+        const float fl = std::floor((cl - lo[a]) / scale[a]), fh = std::ceil((chh - lo[a]) / scale[a]);
+        long ql = fl >= 255.f ? 255L : fl > 0.f ? (long)fl : 0L;
+        long qh = fh >= 255.f ? 255L : fh > 0.f ? (long)fh : (fh == fh ? 0L : 255L);
         while (ql > 0 && decode(lo[a], (uint32_t)ql, scale[a]) > cl) --ql;      // conservative under the device's rounding
         while (qh < 255 && decode(lo[a], (uint32_t)qh, scale[a]) < chh) ++qh;
         if (decode(lo[a], (uint32_t)ql, scale[a]) > cl || decode(lo[a], (uint32_t)qh, scale[a]) < chh) {

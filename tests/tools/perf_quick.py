@@ -1,6 +1,6 @@
 """Quick performance loop for kernel work (not a pytest): times the BASELINE-shaped workloads at reduced spp and prints a
 CRC of every image. The image is a pure function of (scene, seed), so a pure-performance change must keep every CRC.
-Usage: python tests/tools/perf_quick.py [c1 c2 c3 test] [--spp N] [--phases]"""
+Usage: python tests/tools/perf_quick.py [c1 c2 c3 test] [--spp N] [--phases] [--with-read: also the rate with sol_read (device -> host image) inside the timed region]"""
 import _paths  # noqa: F401  (sys.path)
 import sys
 import time
@@ -8,6 +8,9 @@ import zlib
 
 import parity_util as pu
 from solstrale_amd import DeviceScene, RenderConfig, scenes
+
+
+WITH_READ = "--with-read" in sys.argv
 
 
 def run(name, sc, spp, reps=3, phases=False):
@@ -23,7 +26,16 @@ def run(name, sc, spp, reps=3, phases=False):
             best = min(best, time.perf_counter() - t)
         img = ds.read()
         ns = sc.width * sc.height * spp
+        with_read = 1e9
+        for _ in range(reps if WITH_READ else 0):
+            ds.clear()
+            t = time.perf_counter()
+            ds.render(0, spp, pu.SEED)
+            ds.read()
+            with_read = min(with_read, time.perf_counter() - t)
         line = f"{name:10s} {sc.width}x{sc.height}x{spp:<4d} {best * 1e3:9.2f} ms  {ns / best / 1e6:9.1f} Msamples/s  crc {zlib.crc32(img.tobytes()):08x}"
+        if WITH_READ:
+            line += f"  with sol_read to the host: {with_read * 1e3:9.2f} ms  {ns / with_read / 1e6:9.1f} Msamples/s"
         if phases:
             ds.clear()
             ds.render(0, min(spp, 16), pu.SEED, counted=True)
