@@ -494,7 +494,8 @@ int sol_last_kernel_ms(SolScene* scene, float* ms, uint32_t* grid_blocks);
 /* Function-level evaluation of the device code on n rows of host floats (in_stride / out_stride floats per row), for
  * pinning the fp32 arithmetic contract bit for bit (tests/test_gpu_functions.py). fn: 0 arithmetic, 1 elementary
  * functions, 2 RNG, 3 vector ops + Onb::new, 4 Sphere::hit, 5 Quad::hit, 6 Triangle::hit, 7 Aabb::hit, 8 sampling
- * (row layouts: solstrale-rust_amd/csrc/sol_aux.hip, sol_eval_kernel). No reference analogue. */
+ * (row layouts: solstrale-rust_amd/csrc/sol_aux.hip, sol_eval_kernel; floats read / written per row, fn 0..8: 3/7, 3/5, 5/2, 7/18, 13/2,
+ * 24/4, 17/4, 12/2, 4/7 - narrower strides and unknown functions are SOL_EINVAL). No reference analogue. */
 int sol_eval(int device, uint32_t fn, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride);
 
 /* Sizes of the device records, for the algorithmic-bytes formula: node, sphere, quad, triangle

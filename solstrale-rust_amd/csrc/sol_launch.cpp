@@ -24,7 +24,7 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
   HIP_TRY(hipSetDevice(s->device));
   RenderParams P{};
   P.first_sample = first; P.n_samples = n;
-  P.n_chunks = (n + SOL_CHUNK - 1) / SOL_CHUNK;
+  P.n_chunks = (uint32_t)(((uint64_t)n + SOL_CHUNK - 1) / SOL_CHUNK);  // (in 64 bits: n + 15 wraps for the last fifteen values of n)
   P.rank = (uint32_t)s->rank; P.world = (uint32_t)s->world;
   P.n_local_blocks = s->n_local_blocks; P.blocks_x = s->blocks_x;
   P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
@@ -38,7 +38,7 @@ int sol_render_impl(SolScene* s, uint32_t first, uint32_t n, uint64_t seed, bool
     const uint64_t pairs_per_chunk = (uint64_t)s->n_local_blocks;
     const uint64_t max_chunks = std::max<uint64_t>(1, std::min<uint64_t>((6ull << 30) / std::max<uint64_t>(1, pairs_per_chunk * 64u * SOL_CHUNK * 12u),
                                                                          (uint64_t)SOL_MAX_ITEMS / std::max<uint64_t>(1, pairs_per_chunk * 64u * SOL_CHUNK)));
-    if ((uint64_t)(n + SOL_CHUNK - 1) / SOL_CHUNK > max_chunks) {
+    if (((uint64_t)n + SOL_CHUNK - 1) / SOL_CHUNK > max_chunks) {
       uint32_t f = first, left = n;
       while (left) {
         const uint32_t k = (uint32_t)std::min<uint64_t>(left, max_chunks * SOL_CHUNK);
@@ -310,6 +310,12 @@ int sol_read_aux(SolScene* s, float* albedo_sum, float* normal_sum) {
 
 int sol_eval(int device, uint32_t fn, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride) {
   if (!in || !out || !in_stride || !out_stride) return sol_fail(SOL_EINVAL, "bad argument");
+  // floats a row of sol_eval_kernel (sol_aux.hip) reads and writes, per function: a narrower stride would read and write past the device copies
+  static const uint32_t row_in[9] = {3, 3, 5, 7, 13, 24, 17, 12, 4}, row_out[9] = {7, 5, 2, 18, 2, 4, 4, 2, 7};
+  if (fn > 8u) return sol_fail(SOL_EINVAL, "sol_eval: unknown function %u", fn);
+  if (in_stride < row_in[fn] || out_stride < row_out[fn])
+    return sol_fail(SOL_EINVAL, "sol_eval: function %u reads %u and writes %u floats per row (strides %u / %u)", fn, row_in[fn], row_out[fn], in_stride, out_stride);
+  if ((uint64_t)n * std::max(in_stride, out_stride) > (1ull << 32)) return sol_fail(SOL_EINVAL, "sol_eval: more than 2^32 floats");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sol_fail(SOL_EDEVICE, "no HIP device available");
   HIP_TRY(hipSetDevice(device));
