@@ -24,7 +24,7 @@ def comm_unique_id():
     buf = (C.c_uint8 * _abi.UNIQUE_ID_BYTES)()
     rc = lib.sol_comm_unique_id(buf)
     if rc != 0:
-        raise DeviceError(rc, lib.sol_last_error().decode())
+        raise DeviceError(rc, lib.sol_last_error().decode(errors="replace"))
     return bytes(buf)
 
 
@@ -41,7 +41,7 @@ def eval_functions(fn, rows, out_cols, device=0):
     out = np.zeros((a.shape[0], out_cols), dtype=np.float32)
     rc = lib.sol_eval(device, fn, a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data, out_cols)
     if rc != 0:
-        raise DeviceError(rc, lib.sol_last_error().decode())
+        raise DeviceError(rc, lib.sol_last_error().decode(errors="replace"))
     return out
 
 
@@ -51,7 +51,7 @@ def world_tree_check(scene, use_sah):
     out = _abi.SolTreeCheck()
     rc = lib.sol_world_tree_check_ex(scene.desc_ptr, int(use_sah), C.byref(out), C.sizeof(out))  # (the size-prefixed form: every field)
     if rc != 0:
-        raise DeviceError(rc, lib.sol_last_error().decode())
+        raise DeviceError(rc, lib.sol_last_error().decode(errors="replace"))
     return out.as_dict()
 
 
@@ -65,7 +65,7 @@ def background_blocks(scene, use_sah=0):
     n = C.c_uint32()
     rc = lib.sol_background_blocks(scene.desc_ptr, int(use_sah), flags, bx * by, C.byref(n))
     if rc != 0:
-        raise DeviceError(rc, lib.sol_last_error().decode())
+        raise DeviceError(rc, lib.sol_last_error().decode(errors="replace"))
     out = np.frombuffer(flags, dtype=np.uint8).reshape(by, bx).astype(bool)
     assert int(out.sum()) == n.value
     return out
@@ -89,12 +89,12 @@ class DeviceScene:
             rc = self.lib.sol_scene_create_ex(scene.desc_ptr, device, C.byref(opt), C.byref(self.h))
         if rc != 0:
             self.h = None
-            raise DeviceError(rc, self.lib.sol_last_error().decode())
+            raise DeviceError(rc, self.lib.sol_last_error().decode(errors="replace"))
         self.width, self.height = scene.width, scene.height
 
     def _chk(self, rc):
         if rc != 0:
-            raise DeviceError(rc, self.lib.sol_last_error().decode())
+            raise DeviceError(rc, self.lib.sol_last_error().decode(errors="replace"))
 
     def close(self):
         if self.h:

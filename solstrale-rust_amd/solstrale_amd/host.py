@@ -140,10 +140,10 @@ class Scene:
         kinds = (C.c_int * max(1, len(pp)))(*[k for k, _ in pp])
         params = (C.c_double * max(1, 3 * len(pp)))(*[x for _, prm in pp for x in prm])
         if b.lib.solh_set_post_processors(b.h, len(pp), kinds, params) != 0:
-            raise HostError(b.lib.solh_last_error().decode())
+            raise HostError(b.lib.solh_last_error().decode(errors="replace"))
         rc_ = b.lib.solh_ray_trace(b.h, rc.samples_per_pixel, rc.seed, strat, interval_seconds, device, cb, ab, None)
         if rc_ != 0:
-            raise HostError(b.lib.solh_last_error().decode())
+            raise HostError(b.lib.solh_last_error().decode(errors="replace"))
         return events, last[0]
 
 
@@ -162,7 +162,7 @@ class SceneBuilder:
 
     def _chk(self, r):
         if r < 0:
-            raise HostError(self.lib.solh_last_error().decode())
+            raise HostError(self.lib.solh_last_error().decode(errors="replace"))
         return r
 
     def _tf(self, ops):
@@ -251,8 +251,11 @@ class SceneBuilder:
         keep = []
 
         def _decode(_user, cpath, pw, ph, pdata):
-            fn = cpath.decode()
-            if not os.path.isfile(fn):
+            try:
+                fn = os.fsdecode(cpath)  # (a file name is bytes: an MTL may name one that is not UTF-8)
+                if not os.path.isfile(fn):
+                    return 1
+            except (ValueError, OSError):  # (an embedded NUL, a name longer than the file system takes)
                 return 1
             try:
                 a = np.ascontiguousarray(np.asarray(Image.open(fn).convert("RGB"), dtype=np.uint8))
@@ -291,5 +294,5 @@ class SceneBuilder:
                                  camera.aperture_size, _abi.d3(camera.look_from), _abi.d3(camera.look_at),
                                  _abi.d3(camera.up))
         if not p:
-            raise HostError(self.lib.solh_last_error().decode())
+            raise HostError(self.lib.solh_last_error().decode(errors="replace"))
         return Scene(self, p, render_config)

@@ -183,3 +183,66 @@ def test_malformed_obj_and_mtl_are_errors_or_models_never_crashes(name, tmp_path
     for i in range(d.n_triangles):
         t = d.triangles[i]
         assert 0 <= t.material < d.n_materials
+
+
+TOKENS = ["nan", "inf", "-inf", "1e999", "-1e999", "1e-999", "0", "-0", "-1", "1", "2", "99999999999999999999", "-99999999999999999999", "4294967296", "2147483648",
+          "/", "//", "1/", "/1", "1//1", "1/1/1", "-1/-1/-1", "0/0/0", "", " ", "\t", "#", "v", "vt", "vn", "f", "usemtl", "mtllib", "newmtl", "Kd", "map_Kd", "map_bump",
+          "-bm", "g", "o", "s", "l", "p", "\x00", "\xff\xfe", "a" * 300, "../../../etc/passwd", "spider.mtl", "x.mtl", "SpiderTex.jpg", "1.0.0", "1e", "+", "-", "."]
+N_OBJ_MUTATIONS = int(os.environ.get("SOL_TEST_OBJ_MUTATIONS", "250"))  # (a longer campaign: SOL_TEST_OBJ_MUTATIONS=20000 SOL_TEST_OBJ_SEED=k)
+
+
+def _mutate_text(text, rng):
+    """One to four edits of a text file: a token replaced, a line dropped / doubled / moved, bytes inserted, the file cut short."""
+    lines = text.split("\n")
+    for _ in range(int(rng.integers(1, 5))):
+        what = int(rng.integers(7))
+        i = int(rng.integers(len(lines))) if lines else 0
+        if not lines:
+            break
+        if what <= 2:
+            toks = lines[i].split(" ")
+            toks[int(rng.integers(len(toks)))] = TOKENS[int(rng.integers(len(TOKENS)))]
+            lines[i] = " ".join(toks)
+        elif what == 3:
+            del lines[i]
+        elif what == 4:
+            lines.insert(int(rng.integers(len(lines) + 1)), lines[i])
+        elif what == 5:
+            k = int(rng.integers(len(lines[i]) + 1))
+            lines[i] = lines[i][:k] + "".join(chr(int(c)) for c in rng.integers(0, 256, int(rng.integers(1, 9)))) + lines[i][k:]
+        else:
+            lines = lines[: int(rng.integers(len(lines) + 1))]
+            if lines:
+                lines[-1] = lines[-1][: int(rng.integers(len(lines[-1]) + 1))]
+    return "\n".join(lines)
+
+
+@pytest.mark.parametrize("base", ["boxWithMat", "triWithHeightMap", "spider"])
+def test_mutated_obj_and_mtl_files_are_errors_or_models(base, tmp_path):
+    """The hand-written malformed files above, made many: the reference's own OBJ + MTL files with one to four random edits each (tokens replaced by
+    numbers no type holds, indices of every sign and size, stray slashes, keywords in the wrong place, raw bytes, lines dropped, doubled and cut),
+    alternately in the .obj and the .mtl. An error string or a model whose triangles name existing materials; never a crash (also under ASan + UBSan:
+    tests/tools/sanitize.sh). Image files a mutated `map_Kd` names are the directory's real ones, a missing one, or not an image at all."""
+    src = SPIDER_DIR if base == "spider" else OBJ_DIR
+    root = tmp_path / "m"
+    shutil.copytree(src, root)
+    obj0 = open(os.path.join(src, base + ".obj"), encoding="latin-1").read()
+    mtl0 = open(os.path.join(src, base + ".mtl"), encoding="latin-1").read()
+    (root / "x.mtl").write_bytes(b"newmtl a\nKd 1 0 0\n")
+    rng = np.random.default_rng({"boxWithMat": 31, "triWithHeightMap": 32, "spider": 33}[base] + 1000 * int(os.environ.get("SOL_TEST_OBJ_SEED", "0")))
+    n = N_OBJ_MUTATIONS if base != "spider" else max(40, N_OBJ_MUTATIONS // 6)  # (the spider is 106 kB)
+    models = 0
+    for k in range(n):
+        obj, mtl = (_mutate_text(obj0, rng), mtl0) if k % 2 == 0 else (obj0, _mutate_text(mtl0, rng))
+        (root / (base + ".obj")).write_bytes(obj.encode("latin-1"))
+        (root / (base + ".mtl")).write_bytes(mtl.encode("latin-1"))
+        try:
+            sc = _scene_of(lambda b: b.load_obj(str(root) + os.sep, base + ".obj"))
+        except HostError as e:
+            assert str(e)
+            continue
+        models += 1
+        d = sc.desc
+        for i in range(d.n_triangles):
+            assert 0 <= d.triangles[i].material < d.n_materials
+    assert models > n // 10  # (most edits leave a readable file)
