@@ -14,5 +14,5 @@ export LD_PRELOAD="$rt"
 export ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0:verify_asan_link_order=0:detect_odr_violation=0"
 export UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"
 export SOLSTRALE_BUILD_DIR="$san" SOLSTRALE_ORACLE_LIB="$san/liboracle.so"
-python -m pytest tests/test_host.py tests/test_obj_loader.py tests/test_world_tree.py tests/test_oracle_kat.py tests/test_oracle_golden.py tests/test_abi.py tests/test_fp32_contract.py tests/test_background_blocks.py tests/test_gpu_examples.py tests/test_obj_scale.py tests/test_desc_mutations.py \
+python -m pytest tests/test_host.py tests/test_obj_loader.py tests/test_world_tree.py tests/test_oracle_kat.py tests/test_oracle_golden.py tests/test_abi.py tests/test_fp32_contract.py tests/test_background_blocks.py tests/test_gpu_examples.py tests/test_obj_scale.py tests/test_desc_mutations.py tests/test_host_api_sequences.py \
   -q -m "not gpu" -p no:cacheprovider -k "not gfx950_code_object and not missing_communication_library" "$@"
