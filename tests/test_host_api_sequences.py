@@ -1,8 +1,8 @@
 """The C wrappers of the host mirror (include/solstrale_host.h) take plain ints where the reference's Rust API takes owned values: a texture, material,
 transformation or hittable id can be anything a foreign caller passes. Seeded random BUILDER sequences - ids from the valid range, one past it, negative,
 huge; NaN / infinite / zero geometry; empty and self-containing BVHs; a constant medium around a medium; images of zero size - must end in an error
-string or a scene, never in a crash; whatever solh_finish hands out then goes through sol_scene_create's validation (SOL_EDEVICE here: no GPU) and
-the host-side tree diagnostics. Also run under AddressSanitizer + UBSan (tests/tools/sanitize.sh)."""
+string or a scene, never in a crash; whatever solh_finish hands out then goes through sol_scene_create's validation (SOL_EDEVICE without a GPU; with one
+the scene is created, rendered and read back) and the host-side tree diagnostics. Also run under AddressSanitizer + UBSan (tests/tools/sanitize.sh)."""
 import ctypes as C
 import os
 
@@ -131,17 +131,17 @@ class Seq:
         hip = _abi.load_hip()
         hnd = C.c_void_p()
         rc = hip.sol_scene_create(desc, 0, C.byref(hnd))
-        assert rc in (_abi.SOL_EINVAL, _abi.SOL_ENOLIGHT, _abi.SOL_EDEVICE, _abi.SOL_EDEPTH), rc
+        assert rc in (_abi.SOL_OK, _abi.SOL_EINVAL, _abi.SOL_ENOLIGHT, _abi.SOL_EDEVICE, _abi.SOL_EDEPTH), rc
+        if rc == _abi.SOL_OK:  # (a GPU box: whatever the builder made valid is rendered and read back)
+            img = np.zeros((h, w, 3), np.float32)
+            assert hip.sol_render(hnd, 0, 2, 99) == _abi.SOL_OK and hip.sol_read(hnd, img.ctypes.data_as(C.POINTER(C.c_float))) == _abi.SOL_OK
+            hip.sol_scene_destroy(hnd)
         chk = _abi.SolTreeCheck()
         hip.sol_world_tree_check_ex(desc, int(r.integers(0, 3)), C.byref(chk), C.sizeof(chk))
-        return "valid" if rc == _abi.SOL_EDEVICE else "refused"
+        return "valid" if rc in (_abi.SOL_OK, _abi.SOL_EDEVICE) else "refused"
 
 
-@pytest.mark.timeout(900)
-def test_random_builder_sequences_end_in_an_error_or_a_scene():
-    from solstrale_amd import device_count
-    if device_count() > 0:
-        pytest.skip("a CPU test: with a device every valid scene would be created")
+def _run_sequences():
     rng = np.random.default_rng(41 + 1000 * SEED_SHIFT)
     tally = {"error": 0, "valid": 0, "refused": 0}
     refused_calls = 0
@@ -160,3 +160,18 @@ def test_random_builder_sequences_end_in_an_error_or_a_scene():
             s.close()
     print(tally, "refused builder calls:", refused_calls)
     assert tally["valid"] >= N_SEQUENCES // 20 and refused_calls >= N_SEQUENCES
+
+
+@pytest.mark.timeout(900)
+def test_random_builder_sequences_end_in_an_error_or_a_scene():
+    from solstrale_amd import device_count
+    if device_count() > 0:
+        pytest.skip("the GPU form below does the same and renders")
+    _run_sequences()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_random_builder_sequences_render_on_the_device():
+    """The same sequences on a GPU box: every scene the builder and the validation accept is created (device tree build included), rendered and read."""
+    _run_sequences()
