@@ -371,6 +371,13 @@ int sol_gather(SolScene* scene, void* image_dev);
 /* Diagnostic for single-GPU boxes: sends the accumulator to this very rank through the communicator (the grouped
  * ncclSend / ncclRecv pair sol_gather uses) and compares the bytes. */
 int sol_comm_self_check(SolScene* scene);
+/* The same gather for ONE process that drives n GPUs (the way a caller of the reference's ray_trace(), src/lib.rs:93-99, is written): scenes[i] is
+ * rank i of n (sol_scene_set_partition(scenes[i], i, n)), each created on its own device. Waits for every rank's renders, copies the compact
+ * accumulators device to device into rank 0's gather buffer (peer copies; no communicator, RCCL is not loaded) and un-permutes them into rank 0's
+ * image buffer; *image_dev = that buffer (W*H*3 floats, row 0 = top, on scenes[0]'s device, valid until the next gather / read / resolve on
+ * scenes[0]); asynchronous on scenes[0]'s stream - the post-processors (sol_tonemap_rgb8, sol_bloom*) of scenes[0] take it as they take
+ * sol_resolve_image's, sol_read_image copies it to the host. */
+int sol_gather_local(SolScene* const* scenes, int n, void** image_dev);
 int sol_read_image(SolScene* scene, float* rgb_sum);
 /* Largest n_samples one sol_render call accepts for the current partition (the work counter is 32 bits). */
 uint32_t sol_max_samples_per_call(const SolScene* scene);

@@ -149,6 +149,47 @@ int sol_gather(SolScene* s, void* image_dev) {
   return SOL_OK;
 }
 
+// The gather of ONE process that drives several GPUs (the reference's ray_trace() is called from one process: src/lib.rs:93-99): scenes[i] is
+// rank i of n, each on its own device with its own stream; their compact accumulators are copied device to device into rank 0's gather buffer
+// (hipMemcpyPeerAsync: one xGMI hop each, no communicator, no RCCL) and un-permuted there, exactly as sol_gather does with what it received.
+int sol_gather_local(SolScene* const* scenes, int n, void** image_dev) {
+  if (!scenes || n < 1 || !image_dev) return sol_fail(SOL_EINVAL, "bad argument");
+  for (int i = 0; i < n; ++i)
+    if (!scenes[i]) return sol_fail(SOL_EINVAL, "scene %d is null", i);
+  SolScene* root = scenes[0];
+  const size_t floats = root->acc_floats;
+  for (int i = 0; i < n; ++i) {
+    const SolScene* s = scenes[i];
+    if (s->world != n || s->rank != i) return sol_fail(SOL_EINVAL, "scene %d is rank %d of %d, expected rank %d of %d (sol_scene_set_partition)", i, s->rank, s->world, i, n);
+    if (s->S.width != root->S.width || s->S.height != root->S.height || s->acc_floats != floats || s->partition_crc != root->partition_crc)
+      return sol_fail(SOL_EINVAL, "scene %d does not share rank 0's frame and partition", i);
+    for (int j = 0; j < i; ++j)
+      if (scenes[j] == s) return sol_fail(SOL_EINVAL, "scene %d is scene %d again", i, j);
+  }
+  for (int i = 0; i < n; ++i) {  // (every rank's sums are complete before they are copied)
+    HIP_TRY(hipSetDevice(scenes[i]->device));
+    HIP_TRY(hipStreamSynchronize(scenes[i]->stream));
+  }
+  HIP_TRY(hipSetDevice(root->device));
+  if (n == 1) {
+    HIP_TRY(sol_launch_unpermute(root->acc, root->image, root->S.width, root->S.height, root->blocks_x, 1u, 0u, floats, root->slot_of_block, root->stream));
+    *image_dev = root->image;
+    return SOL_OK;
+  }
+  if (root->gathered_floats != floats * (size_t)n) {
+    HIP_TRY(hipStreamSynchronize(root->stream));
+    if (root->gathered) hipFree(root->gathered);
+    root->gathered = nullptr; root->gathered_floats = 0;
+    HIP_TRY(hipMalloc((void**)&root->gathered, floats * (size_t)n * sizeof(float)));
+    root->gathered_floats = floats * (size_t)n;
+  }
+  for (int i = 0; i < n; ++i)
+    HIP_TRY(hipMemcpyPeerAsync(root->gathered + (size_t)i * floats, root->device, scenes[i]->acc, scenes[i]->device, floats * sizeof(float), root->stream));
+  HIP_TRY(sol_launch_unpermute(root->gathered, root->image, root->S.width, root->S.height, root->blocks_x, (uint32_t)n, 0xFFFFFFFFu, floats, root->slot_of_block, root->stream));
+  *image_dev = root->image;
+  return SOL_OK;
+}
+
 // Diagnostic for boxes with ONE GPU (where no second rank can exist): moves this rank's accumulator to itself through the
 // communicator - grouped ncclSend + ncclRecv with peer = own rank, the same calls sol_gather issues - and compares the bytes.
 int sol_comm_self_check(SolScene* s) {

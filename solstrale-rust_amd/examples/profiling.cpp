@@ -4,7 +4,8 @@
 // create_test_scene (tests/scenes.rs:17-122) at 800 x 400 with 1000 samples per pixel, ray_trace() draining the progress
 // stream, the last image saved.
 //
-//   profiling [--width W] [--height H] [--spp N] [--seed S] [--device D] [--texture tex.ppm] [--out out.ppm] [--repeat R]
+//   profiling [--width W] [--height H] [--spp N] [--seed S] [--device D | --devices D0,D1,..] [--texture tex.ppm] [--out out.ppm] [--repeat R]
+//   (--devices: the same picture from this one process on several GPUs of the node - ray_trace(scene, output, abort, devices))
 //
 // The reference loads resources/textures/tex.jpg; file decoding is the caller's business on this side of the boundary
 // (DESIGN.md 10), so the ground texture comes as a binary PPM (P6) - tests/test_gpu_examples.py converts the reference's
@@ -16,6 +17,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <vector>
 
 #include "../host/solstrale.hpp"
 
@@ -116,7 +118,8 @@ int main(int argc, char** argv) {
   config.height = 400;
   config.samples_per_pixel = 1000;
   std::string texture, out = "out.ppm";
-  int device = 0, repeat = 1;
+  int repeat = 1;
+  std::vector<int> devices{0};
   for (int a = 1; a < argc; ++a) {
     const std::string k = argv[a];
     auto value = [&]() -> const char* {
@@ -127,7 +130,11 @@ int main(int argc, char** argv) {
     else if (k == "--height") config.height = (size_t)std::strtoul(value(), nullptr, 10);
     else if (k == "--spp") config.samples_per_pixel = (uint32_t)std::strtoul(value(), nullptr, 10);
     else if (k == "--seed") config.seed = std::strtoull(value(), nullptr, 0);
-    else if (k == "--device") device = std::atoi(value());
+    else if (k == "--device") devices = {std::atoi(value())};
+    else if (k == "--devices") {
+      devices.clear();
+      for (const char* p = value(); *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+    }
     else if (k == "--texture") texture = value();
     else if (k == "--out") out = value();
     else if (k == "--repeat") repeat = std::atoi(value());
@@ -144,7 +151,7 @@ int main(int argc, char** argv) {
       const std::string err = ray_trace(scene, [&](RenderProgress&& p) {
         ++events;
         if (p.has_image) last = std::move(p);
-      }, nullptr, device);
+      }, nullptr, devices);
       if (!err.empty()) { std::fprintf(stderr, "profiling: %s\n", err.c_str()); return 1; }
       best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
@@ -155,8 +162,8 @@ int main(int argc, char** argv) {
     if (!f) { std::fprintf(stderr, "profiling: cannot write %s\n", out.c_str()); return 1; }
     const double samples = (double)config.width * (double)config.height * (double)config.samples_per_pixel;
     std::printf("{\"workload\": \"reference profiling binary (create_test_scene)\", \"width\": %zu, \"height\": %zu, \"spp\": %u, \"progress_events\": %u, "
-                "\"ray_trace_s\": %.4f, \"msamples_per_s\": %.1f, \"texture\": \"%s\", \"image\": \"%s\"}\n",
-                config.width, config.height, config.samples_per_pixel, events, best, samples / best / 1e6,
+                "\"ray_trace_s\": %.4f, \"msamples_per_s\": %.1f, \"devices\": %zu, \"texture\": \"%s\", \"image\": \"%s\"}\n",
+                config.width, config.height, config.samples_per_pixel, events, best, samples / best / 1e6, devices.size(),
                 texture.empty() ? "procedural checker" : texture.c_str(), out.c_str());
   } catch (const std::exception& e) {
     std::fprintf(stderr, "profiling: %s\n", e.what());

@@ -309,6 +309,10 @@ std::unique_ptr<FlatScene> flatten(const Scene& scene);
 // (e.g. "Scene should have at least one light").
 std::string ray_trace(const Scene& scene, const std::function<void(RenderProgress&&)>& output,
                       const std::function<bool()>& abort, int device = 0);
+// The same from ONE process on several GPUs of the node (extension; the picture does not depend on how many): the frame's 8x8 blocks are dealt out
+// over `devices`, each holds the scene and renders its blocks of every batch; images are gathered into devices[0] by peer copies (sol_gather_local).
+std::string ray_trace(const Scene& scene, const std::function<void(RenderProgress&&)>& output,
+                      const std::function<bool()>& abort, const std::vector<int>& devices);
 
 // src/util/rgb_color.rs:14-35 (host-side reference arithmetic for the Nop post-processor)
 void to_rgb_color(const double col[3], uint32_t samples_per_pixel, uint8_t out[3]);

@@ -522,17 +522,44 @@ PostProcessors BloomPostProcessor::create(double kernel_size_fraction, double th
 // ---- ray_trace (src/lib.rs:93-99, src/renderer/mod.rs:140-162,209-358) ---------------------------------------
 std::string ray_trace(const Scene& scene, const std::function<void(RenderProgress&&)>& output,
                       const std::function<bool()>& abort, int device) {
+  return ray_trace(scene, output, abort, std::vector<int>{device});
+}
+
+// The same on several GPUs of the node, from this one process (no reference analogue: its Rayon pool has no devices): the frame's 8x8
+// blocks are dealt out over `devices` (block b -> devices[b mod n]: sol_scene_set_partition), every device holds the scene (created in parallel, one
+// thread each) and renders its blocks of every batch concurrently; an image is gathered into the first device (sol_gather_local: peer copies) and
+// post-processed there. The picture does not depend on n (RNG key = (seed, pixel, sample)). A device may be named more than once.
+std::string ray_trace(const Scene& scene, const std::function<void(RenderProgress&&)>& output,
+                      const std::function<bool()>& abort, const std::vector<int>& devices) {
   // Renderer::new
   if (get_lights(scene.world).empty()) return "Scene should have at least one light";
+  if (devices.empty()) return "ray_trace: no device named";
   std::unique_ptr<FlatScene> fs;
   try {
     fs = flatten(scene);
   } catch (const std::exception& e) {
     return e.what();
   }
-  SolScene* dev = nullptr;
-  if (sol_scene_create(&fs->desc, device, &dev) != SOL_OK) return sol_last_error();
-  struct Guard { SolScene* s; ~Guard() { sol_scene_destroy(s); } } guard{dev};
+  const int n_dev = (int)devices.size();
+  std::vector<SolScene*> devs((size_t)n_dev, nullptr);
+  struct Guard { std::vector<SolScene*>& v; ~Guard() { for (SolScene* s : v) sol_scene_destroy(s); } } guard{devs};
+  if (n_dev == 1) {
+    if (sol_scene_create(&fs->desc, devices[0], &devs[0]) != SOL_OK) return sol_last_error();
+  } else {
+    std::vector<std::string> errs((size_t)n_dev);
+    std::vector<std::thread> pool;
+    for (int i = 0; i < n_dev; ++i)
+      pool.emplace_back([&, i] {  // (sol_last_error is per thread: read where the call was made)
+        if (sol_scene_create(&fs->desc, devices[(size_t)i], &devs[(size_t)i]) != SOL_OK || sol_scene_set_partition(devs[(size_t)i], i, n_dev) != SOL_OK) {
+          errs[(size_t)i] = sol_last_error();
+          if (errs[(size_t)i].empty()) errs[(size_t)i] = "scene creation failed";
+        }
+      });
+    for (auto& t : pool) t.join();
+    for (const std::string& e : errs)
+      if (!e.empty()) return e;
+  }
+  SolScene* const dev = devs[0];
 
   const RenderConfig& rc = scene.render_config;
   const uint32_t spp = rc.samples_per_pixel;
@@ -553,14 +580,17 @@ std::string ray_trace(const Scene& scene, const std::function<void(RenderProgres
   const bool interval = rc.render_image_strategy.kind == RenderImageStrategy::Interval;
   const double grow_below = only_final ? 0.05 : interval ? std::min(0.05, 0.5 * rc.render_image_strategy.interval_seconds) : 0.0;
   if (only_final) batch = 64u;
-  const uint32_t batch_cap = std::max(16u, sol_max_samples_per_call(dev) / 16u * 16u);
+  uint32_t batch_cap = 0xFFFFFFF0u;
+  for (SolScene* d : devs) batch_cap = std::min(batch_cap, std::max(16u, sol_max_samples_per_call(d) / 16u * 16u));
   uint32_t done = 0;
   while (done < spp) {
     if (abort && abort()) return "";
     uint32_t n = std::min(std::min(batch, batch_cap), spp - done);
     const double t_batch = secs(clk::now());
-    if (sol_render(dev, done, n, rc.seed) != SOL_OK) return sol_last_error();
-    if (sol_sync(dev) != SOL_OK) return sol_last_error();
+    for (SolScene* d : devs)  // (asynchronous: the devices render their blocks of this batch side by side)
+      if (sol_render(d, done, n, rc.seed) != SOL_OK) return sol_last_error();
+    for (SolScene* d : devs)
+      if (sol_sync(d) != SOL_OK) return sol_last_error();
     if (secs(clk::now()) - t_batch < grow_below && batch < batch_cap) batch *= 2u;
     for (uint32_t s = done + 1; s <= done + n; ++s) {
       double now = secs(clk::now());
@@ -573,7 +603,7 @@ std::string ray_trace(const Scene& scene, const std::function<void(RenderProgres
         // (intermediate_post_process), the last one produces the image; an empty list produces none
         if (!rc.post_processors.empty()) {
           void* img = nullptr;
-          if (sol_resolve_image(dev, &img) != SOL_OK) return sol_last_error();
+          if ((n_dev == 1 ? sol_resolve_image(dev, &img) : sol_gather_local(devs.data(), n_dev, &img)) != SOL_OK) return sol_last_error();
           for (size_t k = 0; k + 1 < rc.post_processors.size(); ++k) {
             const PostProcessors& pp = rc.post_processors[k];
             if (pp.kind == PostProcessors::Bloom &&

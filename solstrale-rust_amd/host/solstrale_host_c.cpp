@@ -245,8 +245,14 @@ uint32_t solh_tree_depth(const SolhBuilder* b) { return b->flat ? b->flat->max_d
 
 int solh_ray_trace(SolhBuilder* b, uint32_t spp, uint64_t seed, int strategy, double interval_seconds, int device,
                    solh_progress_fn progress, solh_abort_fn abort_cb, void* user) {
+  return solh_ray_trace_devices(b, spp, seed, strategy, interval_seconds, 1, &device, progress, abort_cb, user);
+}
+
+int solh_ray_trace_devices(SolhBuilder* b, uint32_t spp, uint64_t seed, int strategy, double interval_seconds, int n_devices, const int* devices,
+                           solh_progress_fn progress, solh_abort_fn abort_cb, void* user) {
   return guarded([&] {
     if (!b->scene.world) throw std::runtime_error("solh_ray_trace: call solh_finish first");
+    if (n_devices < 1 || n_devices > 64 || !devices) throw std::runtime_error("solh_ray_trace_devices: 1 .. 64 devices");
     Scene& s = b->scene;
     s.render_config.samples_per_pixel = spp;
     s.render_config.seed = seed;
@@ -259,7 +265,7 @@ int solh_ray_trace(SolhBuilder* b, uint32_t spp, uint64_t seed, int strategy, do
           if (progress)
             progress(user, p.progress, p.fps, p.estimated_time_left_s, p.has_image ? p.render_image.data() : nullptr, p.width, p.height);
         },
-        [&]() { return abort_cb ? abort_cb(user) != 0 : false; }, device);
+        [&]() { return abort_cb ? abort_cb(user) != 0 : false; }, std::vector<int>(devices, devices + n_devices));
     if (!err.empty()) throw std::runtime_error(err);
     return 0;
   });

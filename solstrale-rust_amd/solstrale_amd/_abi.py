@@ -209,6 +209,7 @@ def load_hip():
     _sig(lib, "sol_comm_destroy", C.c_int, [P])
     _sig(lib, "sol_gather", C.c_int, [P, C.c_void_p])
     _sig(lib, "sol_comm_self_check", C.c_int, [P])
+    _sig(lib, "sol_gather_local", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)])
     _sig(lib, "sol_read_image", C.c_int, [P, C.POINTER(C.c_float)])
     _sig(lib, "sol_max_samples_per_call", C.c_uint32, [P])
     _libs["hip"] = lib
@@ -221,7 +222,7 @@ HIP_SYMBOLS = ["sol_device_count", "sol_scene_create", "sol_scene_destroy", "sol
                "sol_stats", "sol_record_sizes", "sol_last_error", "sol_eval", "sol_kernel_timing", "sol_last_kernel_ms",
                "sol_debug_path", "sol_resolve_image", "sol_bloom", "sol_bloom_rgb8", "sol_gaussian_blur_weights", "sol_world_tree_check", "sol_world_tree_check_ex", "sol_render_aux", "sol_clear_aux", "sol_read_aux",
                "sol_scene_create_ex", "sol_scene_build_times", "sol_scene_set_option", "sol_scene_info", "sol_path_stats", "sol_comm_unique_id", "sol_comm_init",
-               "sol_comm_destroy", "sol_gather", "sol_comm_self_check", "sol_read_image", "sol_max_samples_per_call", "sol_background_blocks"]
+               "sol_comm_destroy", "sol_gather", "sol_gather_local", "sol_comm_self_check", "sol_read_image", "sol_max_samples_per_call", "sol_background_blocks"]
 
 
 def load_host():
@@ -260,6 +261,7 @@ def load_host():
     _sig(lib, "solh_environment", I, [B, C.c_uint32, C.c_uint32, C.c_void_p, D])
     _sig(lib, "solh_tree_depth", C.c_uint32, [B])
     _sig(lib, "solh_ray_trace", I, [B, C.c_uint32, C.c_uint64, I, D, I, PROGRESS_FN, ABORT_FN, C.c_void_p])
+    _sig(lib, "solh_ray_trace_devices", I, [B, C.c_uint32, C.c_uint64, I, D, I, C.POINTER(C.c_int), PROGRESS_FN, ABORT_FN, C.c_void_p])
     _sig(lib, "solh_load_obj", I, [B, C.c_char_p, C.c_char_p, I, I, IMAGE_DECODER_FN, C.c_void_p])
     _sig(lib, "solh_set_post_processors", I, [B, I, C.POINTER(C.c_int), C.POINTER(C.c_double)])
     _sig(lib, "solh_abi_sizes", None, [C.POINTER(C.c_uint32)])
@@ -272,7 +274,7 @@ HOST_SYMBOLS = ["solh_builder_new", "solh_builder_free", "solh_last_error", "sol
                 "solh_image_map", "solh_normal_texture", "solh_lambertian", "solh_metal", "solh_dielectric",
                 "solh_diffuse_light", "solh_blend", "solh_sphere", "solh_quad", "solh_box", "solh_triangle",
                 "solh_triangles", "solh_spheres", "solh_constant_medium", "solh_bvh", "solh_bvh_range", "solh_finish",
-                "solh_tree_depth", "solh_environment", "solh_ray_trace", "solh_abi_sizes", "solh_to_rgb_color", "solh_set_post_processors", "solh_load_obj"]
+                "solh_tree_depth", "solh_environment", "solh_ray_trace", "solh_ray_trace_devices", "solh_abi_sizes", "solh_to_rgb_color", "solh_set_post_processors", "solh_load_obj"]
 
 
 def d3(v):

@@ -114,8 +114,9 @@ class Scene:
     def height(self):
         return int(self.desc.height)
 
-    def ray_trace(self, strategy="only_final", interval_seconds=0.0, device=0, abort=None, on_progress=None):
-        """`ray_trace(scene, output, abort)` (src/lib.rs:93-99). Returns (list of progress tuples, last image)."""
+    def ray_trace(self, strategy="only_final", interval_seconds=0.0, device=0, abort=None, on_progress=None, devices=None):
+        """`ray_trace(scene, output, abort)` (src/lib.rs:93-99). Returns (list of progress tuples, last image). `devices` (a list of device
+        ordinals, an ordinal may repeat): the same from this one process on several GPUs (solh_ray_trace_devices)."""
         b = self._builder
         rc = self.render_config
         events = []
@@ -141,7 +142,11 @@ class Scene:
         params = (C.c_double * max(1, 3 * len(pp)))(*[x for _, prm in pp for x in prm])
         if b.lib.solh_set_post_processors(b.h, len(pp), kinds, params) != 0:
             raise HostError(b.lib.solh_last_error().decode(errors="replace"))
-        rc_ = b.lib.solh_ray_trace(b.h, rc.samples_per_pixel, rc.seed, strat, interval_seconds, device, cb, ab, None)
+        if devices is None:
+            rc_ = b.lib.solh_ray_trace(b.h, rc.samples_per_pixel, rc.seed, strat, interval_seconds, device, cb, ab, None)
+        else:
+            ids = (C.c_int * max(1, len(devices)))(*devices)
+            rc_ = b.lib.solh_ray_trace_devices(b.h, rc.samples_per_pixel, rc.seed, strat, interval_seconds, len(devices), ids, cb, ab, None)
         if rc_ != 0:
             raise HostError(b.lib.solh_last_error().decode(errors="replace"))
         return events, last[0]
