@@ -246,3 +246,23 @@ def test_mutated_obj_and_mtl_files_are_errors_or_models(base, tmp_path):
         for i in range(d.n_triangles):
             assert 0 <= d.triangles[i].material < d.n_materials
     assert models > n // 10  # (most edits leave a readable file)
+
+
+def test_vertex_numbers_follow_rusts_f32_grammar(tmp_path):
+    """tobj reads `v` / `vt` with `str::parse::<f32>`: an optional sign, digits with an optional fraction and exponent, or inf / infinity / nan - the whole
+    token, nothing around it; values beyond f32 round to +-inf / 0. The loader's scan (std::from_chars, no allocation per line) is held to the same grammar:
+    a C hex float or a trailing unit is an error, as it is for the reference."""
+    f32 = lambda x: float(np.float32(x))
+    good = {"1.5": 1.5, "+1.5": 1.5, "-2": -2.0, ".5": 0.5, "5.": 5.0, "1e3": 1000.0, "+.5E-3": f32(0.0005), "1e999": float("inf"), "-1e999": float("-inf"),
+            "1e-999": 0.0, "3.4028234e38": f32(3.4028234e38), "0.1": f32(0.1), "16777217": 16777216.0}
+    for tok, want in good.items():
+        (tmp_path / "g.obj").write_text(f"v {tok} 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+        sc = _scene_of(lambda b: b.load_obj(str(tmp_path) + os.sep, "g.obj"))
+        assert sc.desc.n_triangles == 1
+        xs = sorted({float(v[0]) for tri in _triangles(sc) for v in tri} - {0.0, 1.0}) or [0.0 if want == 0.0 else 1.0]
+        if np.isfinite(want) and want not in (0.0, 1.0):
+            assert xs == [want], (tok, xs, want)
+    for tok in ("0x1p3", "1.5abc", "1,5", "--1", "+-1", "++1", "+", "-", ".", "e5", "1e", "1e+", "1_000", ""):
+        (tmp_path / "b.obj").write_text(f"v {tok} 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n" if tok else "v  \nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+        with pytest.raises(HostError):
+            _scene_of(lambda b: b.load_obj(str(tmp_path) + os.sep, "b.obj"))
