@@ -285,9 +285,10 @@ typedef struct SolCreateOptions {
   int32_t split_percent;    /* device build: triangle pre-splitting may add this many references, in percent of the primitive
                                count (a split triangle gets one record per part of it). 0: the default - a budget of 30, used
                                only when it shrinks the summed box area of the primitives below 85 % (meshes of uniform small
-                               triangles stay unsplit); > 0: that budget, always used; < 0: no pre-splitting                   */
+                               triangles stay unsplit); > 0: that budget (at most 1000), always used; < 0: no pre-splitting   */
   int32_t reinsertion_rounds; /* device build: rounds of parallel reinsertion after the clustering (every node looks for the place
-                               where its sub-tree adds the least surface area; results do not change). 0: the default, < 0: none  */
+                               where its sub-tree adds the least surface area; results do not change). 0: the default (8), < 0: none,
+                               at most 1024 (the rounds end when nothing moves)                                                  */
   int32_t no_background_blocks; /* 1: do not look for background blocks (below, SolSceneInfo::background_blocks)            */
   int32_t reserved[2];
 } SolCreateOptions;

@@ -553,6 +553,8 @@ int sol_scene_create_ex(const SolSceneDesc* d, int device, const SolCreateOption
     std::memcpy(&opt, opt_in, std::min<size_t>(opt_in->size, sizeof opt));
   }
   if (opt.world_tree < SOL_TREE_AUTO || opt.world_tree > SOL_TREE_HOST_PROBE) return sol_fail(SOL_EINVAL, "bad world_tree option %d", opt.world_tree);
+  if (opt.split_percent > 1000 || opt.reinsertion_rounds > 1024)  // (a typo must not become a build of hours: ten times the references, a thousand rounds)
+    return sol_fail(SOL_EINVAL, "SolCreateOptions: split_percent %d (at most 1000) / reinsertion_rounds %d (at most 1024)", opt.split_percent, opt.reinsertion_rounds);
   const auto t_begin = std::chrono::steady_clock::now();
   auto seconds_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   if (d->abi_version != SOL_ABI_VERSION && d->abi_version != 1u) return sol_fail(SOL_EINVAL, "abi_version %u, expected %u (or 1)", d->abi_version, SOL_ABI_VERSION);

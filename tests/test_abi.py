@@ -131,3 +131,25 @@ def test_tree_check_keeps_its_first_layout_for_old_bindings():
     assert lib.sol_world_tree_check_ex(sc.desc_ptr, 0, C.byref(full), C.sizeof(full)) == 0
     assert bytes(buf[:48]) == bytes(full)[:48] and full.n_wide >= 1 and full.leaf_mismatches == 0
     assert lib.sol_world_tree_check_ex(sc.desc_ptr, 0, C.byref(full), 40) == _abi.SOL_EINVAL
+
+
+def test_creation_options_are_checked_before_the_device():
+    """SolCreateOptions: an unknown tree choice, a size field no version of the struct had, a pre-splitting budget or a number of reinsertion rounds that
+    can only be a typo (a build of hours) are SOL_EINVAL - also without a GPU."""
+    import ctypes as C
+    lib = _abi.load_hip()
+    sc = scenes.cornell_box(RenderConfig(16, 16, 1))
+    for field, value in (("world_tree", 99), ("world_tree", -9), ("size", 4), ("size", 1 << 20), ("split_percent", 1001), ("split_percent", 0x7FFFFFFF),
+                         ("reinsertion_rounds", 1025), ("reinsertion_rounds", 0x7FFFFFFF)):
+        opt = _abi.SolCreateOptions()
+        opt.size = C.sizeof(opt)
+        setattr(opt, field, value)
+        h = C.c_void_p()
+        assert lib.sol_scene_create_ex(sc.desc_ptr, 0, C.byref(opt), C.byref(h)) == _abi.SOL_EINVAL, (field, value)
+    opt = _abi.SolCreateOptions()
+    opt.size = C.sizeof(opt)
+    opt.split_percent, opt.reinsertion_rounds = 1000, 1024
+    h = C.c_void_p()
+    assert lib.sol_scene_create_ex(sc.desc_ptr, 0, C.byref(opt), C.byref(h)) in (_abi.SOL_EDEVICE, _abi.SOL_OK)
+    if h:
+        lib.sol_scene_destroy(h)
