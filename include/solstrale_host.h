@@ -98,7 +98,7 @@ typedef int (*solh_abort_fn)(void* user);
 int solh_ray_trace(SolhBuilder* b, uint32_t samples_per_pixel, uint64_t seed, int strategy, double interval_seconds,
                    int device, solh_progress_fn progress, solh_abort_fn abort_cb, void* user);
 /* The same from one process on n_devices GPUs of the node (extension: the reference has no devices): the frame's 8x8 blocks are dealt out over
- * `devices` (block b -> devices[b mod n]); every device holds the scene and renders its blocks of each batch, images are gathered into devices[0]
+ * `devices` (by their cost in the creation probe); every device holds the scene and renders its blocks of each batch, images are gathered into devices[0]
  * by peer copies (sol_gather_local) and post-processed there. The picture does not depend on n_devices. A device may be named more than once. */
 int solh_ray_trace_devices(SolhBuilder* b, uint32_t samples_per_pixel, uint64_t seed, int strategy, double interval_seconds,
                            int n_devices, const int* devices, solh_progress_fn progress, solh_abort_fn abort_cb, void* user);

@@ -555,7 +555,7 @@ std::string ray_trace(const Scene& scene, const std::function<void(RenderProgres
 }
 
 // The same on several GPUs of the node, from this one process (no reference analogue: its Rayon pool has no devices): the frame's 8x8
-// blocks are dealt out over `devices` (block b -> devices[b mod n]: sol_scene_set_partition), every device holds the scene (created in parallel, one
+// blocks are dealt out over `devices` (by their cost in the creation probe: SOL_OPT_BALANCED_PARTITION + sol_scene_set_partition), every device holds the scene (created in parallel, one
 // thread each) and renders its blocks of every batch concurrently; an image is gathered into the first device (sol_gather_local: peer copies) and
 // post-processed there. The picture does not depend on n (RNG key = (seed, pixel, sample)). A device may be named more than once.
 std::string ray_trace(const Scene& scene, const std::function<void(RenderProgress&&)>& output,
@@ -579,7 +579,10 @@ std::string ray_trace(const Scene& scene, const std::function<void(RenderProgres
     std::vector<std::thread> pool;
     for (int i = 0; i < n_dev; ++i)
       pool.emplace_back([&, i] {  // (sol_last_error is per thread: read where the call was made)
-        if (sol_scene_create(&fs->desc, devices[(size_t)i], &devs[(size_t)i]) != SOL_OK || sol_scene_set_partition(devs[(size_t)i], i, n_dev) != SOL_OK) {
+        // (the blocks are dealt out by their cost in the creation probe - deterministic, the same table on every device: sol_gather_local compares the
+        // checksums - instead of b mod n: the devices finish a batch within a block's cost of each other)
+        if (sol_scene_create(&fs->desc, devices[(size_t)i], &devs[(size_t)i]) != SOL_OK ||
+            sol_scene_set_option(devs[(size_t)i], SOL_OPT_BALANCED_PARTITION, 1) != SOL_OK || sol_scene_set_partition(devs[(size_t)i], i, n_dev) != SOL_OK) {
           errs[(size_t)i] = sol_last_error();
           if (errs[(size_t)i].empty()) errs[(size_t)i] = "scene creation failed";
         }
