@@ -176,7 +176,8 @@ const double RAY_MIN = 0.001;     // RAY_INTERVAL (interval.rs:25-28)
 
 template <typename R> struct Ray {
   V3<R> origin, direction, inv;
-  static Ray make(const V3<R>& o, const V3<R>& d) { return {o, d, {(R)1 / d.x, (R)1 / d.y, (R)1 / d.z}}; }  // geo/mod.rs:277-285
+  uint32_t from = 0;  // (fp32 rule 8, float instantiation only) the quad / triangle this ray leaves, 0 = none
+  static Ray make(const V3<R>& o, const V3<R>& d) { return {o, d, {(R)1 / d.x, (R)1 / d.y, (R)1 / d.z}, 0u}; }  // geo/mod.rs:277-285
   V3<R> at(R t) const { return origin + direction * t; }
 };
 
@@ -732,7 +733,17 @@ template <typename R> struct Tracer {
     if (live) cnt.live_rays++;  // (OrcStats::live_rays: the rays the device traces too)
     cur_depth = depth;
     Cand<R> c;
-    const bool any_hit = hit_ref(sc.root, ray, (R)RAY_MIN, std::numeric_limits<R>::infinity(), c);
+    bool any_hit = hit_ref(sc.root, ray, (R)RAY_MIN, std::numeric_limits<R>::infinity(), c);
+    // fp32 rule 8 (float instantiation only): a ray does not hit the FLAT primitive it leaves. A line meets a plane once, and the ray starts on
+    // it: in f64 the second "hit" lies at t ~ 1e-11, far below RAY_MIN, and never counts (the reference's behaviour); in fp32 the start point is a few
+    // 1e-5 off its plane at coordinates of hundreds, and a grazing ray (|n.d| of a few per cent) finds the plane again at t just above RAY_MIN = 1e-3 - from
+    // C1's camera 7 samples in a million went into the box they had just left and came back black. When the closest hit is that primitive, the search is
+    // repeated behind it.
+    if (sizeof(R) == 4 && any_hit && ray.from != 0u && c.ref == ray.from) {
+      Cand<R> behind;
+      any_hit = hit_ref(sc.root, ray, std::nextafter(c.t, std::numeric_limits<R>::infinity()), std::numeric_limits<R>::infinity(), behind);
+      if (any_hit) c = behind;
+    }
     if (trace) {
       uint32_t rb = any_hit ? c.ref : 0u;
       float rf; std::memcpy(&rf, &rb, 4);
@@ -762,6 +773,7 @@ template <typename R> struct Tracer {
       const V3<R> a = s.color * s.probability;
       if (!(a.x > (R)0 || a.y > (R)0 || a.z > (R)0)) live = false;
     }
+    s.ray.from = (SOL_REF_KIND(c.ref) == SOL_REF_QUAD || SOL_REF_KIND(c.ref) == SOL_REF_TRIANGLE) ? c.ref : 0u;  // (rule 8: the scattered ray starts on this primitive)
     AttCol child = ray_color(s.ray, depth + 1, total);
     if (s.type == 1) return {s.color * child.color, child.has_af, child.af, child.len};
     V3<R> sc_col = s.color * s.probability * child.color;

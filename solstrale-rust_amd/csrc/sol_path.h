@@ -12,8 +12,31 @@ struct Path {
   float acc_len;  // accumulated_ray_length (sum of parametric t, shader.rs:74)
   uint32_t depth;
   bool pdf_seen;
+  uint32_t from;  // fp32 rule 8: the quad / triangle the current ray leaves, as 2^31 | its depth-first index (0: a camera ray, a sphere,
+                  // a medium) - sol_self_hit. (The dfs index, not the reference: a pre-split triangle has one record per part, all with its dfs index.)
   Rng rng;
 };
+
+// fp32 rule 8: a ray does not hit the FLAT primitive it leaves. A line meets a plane once and the ray starts on it - in f64 the second "hit" lies at
+// t ~ 1e-11, far below RAY_MIN, and never counts; in fp32 the start point is a few 1e-5 off its plane at coordinates of hundreds and a grazing ray finds
+// the plane again just above RAY_MIN (C1: 7 samples in a million went into the box they had just left and came back black; found by the 1024-spp
+// run of the f64 gate). True when the closest hit `h` of a finished world search is that primitive: the caller searches again BEHIND it
+// (tmin = sol_behind(h.t); the oracle's float instantiation does the same: oracle.cpp ray_color).
+#ifndef SOL_RULE8
+#define SOL_RULE8 1  // (0: an A/B build without the rule - tests/tools/variants.py -, for pricing it; its frames are not the oracle's)
+#endif
+DEV bool sol_self_hit(uint32_t from, const Hit& h) { return SOL_RULE8 && from != 0u && (0x80000000u | h.dfs) == from && SOL_REF_KIND(h.ref) != SOL_REF_NONE; }
+DEV float sol_behind(float t) { return __uint_as_float(__float_as_uint(t) + 1u); }  // (the next float above a positive finite t: std::nextafter's)
+// Path::from of a ray that starts on the primitive of hit `h`. The product kernel's hits carry their dfs index; the A/B kernels park a hit without it
+// (Hit::dfs = SOL_DFS_UNKNOWN on adoption): then it is read from the primitive's record.
+#define SOL_DFS_UNKNOWN 0xFFFFFFFFu
+DEV uint32_t sol_flat_from(const DevScene& S, const Hit& h) {
+  const uint32_t kind = SOL_REF_KIND(h.ref), idx = SOL_REF_INDEX(h.ref);
+  if (kind != SOL_REF_TRIANGLE && kind != SOL_REF_QUAD) return 0u;
+  uint32_t dfs = h.dfs;
+  if (dfs == SOL_DFS_UNKNOWN) dfs = kind == SOL_REF_TRIANGLE ? ldg_u32(&S.tris[idx].dfs) : ldg_u32(&S.quads[idx].dfs);
+  return 0x80000000u | dfs;
+}
 
 // Pixel jitter + Camera::get_ray (src/renderer/mod.rs:263-265, src/camera.rs:77-89) for sample `s` of pixel (px, py),
 // py counted from the image top.
@@ -46,6 +69,7 @@ DEV void generate_path(const DevScene& S, uint32_t seed_lo, uint32_t seed_hi, ui
   p.acc_len = 0.0f;
   p.depth = 0;
   p.pdf_seen = false;
+  p.from = 0u;
 }
 
 DEV f3 ray_inverse(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }  // Ray::new (geo/mod.rs:277-285)
@@ -119,6 +143,7 @@ DEV bool shade_vertex(const DevScene& S, Path& p, const Hit& h, f3& contrib, Cou
           p.d = sc.dir;
           p.acc_len = total;
           p.depth++;
+          p.from = SOL_RULE8 ? sol_flat_from(S, h) : 0u;  // (rule 8: the scattered ray starts on this primitive)
         }
       }
     }

@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) v2u lds_u2;
 
 // A context's records (LDS, [record][slot of the workgroup]):
 //   0: o.xyz, accumulated ray length     1: d.xyz, depth | pdf_seen << 31     2: A.xyz, rng.k0     3: C.xyz, rng.k1
-//   4: hit t, reference, u, v (a parked HIT only)                              5 (two dwords): rng.ctr, out_at
+//   4: hit t, reference, u, v (a parked HIT); Path::from in .x (a parked RAY: rule 8)   5 (two dwords): rng.ctr, out_at
 struct PoolCtx {
   v4u r0, r1, r2, r3, r4;
   v2u r5;
@@ -127,12 +127,13 @@ sol_render_pool4_kernel(const DevScene* __restrict__ Sp, const RenderParams P, f
     rec4[1 * SOL_WG + (slot)] = (v4u){__float_as_uint(p.d.x), __float_as_uint(p.d.y), __float_as_uint(p.d.z), p.depth | (p.pdf_seen ? 0x80000000u : 0u)}; \
     rec4[2 * SOL_WG + (slot)] = (v4u){__float_as_uint(p.A.x), __float_as_uint(p.A.y), __float_as_uint(p.A.z), p.rng.k0};           \
     rec4[3 * SOL_WG + (slot)] = (v4u){__float_as_uint(p.C.x), __float_as_uint(p.C.y), __float_as_uint(p.C.z), p.rng.k1};           \
+    rec4[4 * SOL_WG + (slot)] = (v4u){p.from, 0u, 0u, 0u}; /* (a parked hit overwrites it: its search is over) */                   \
     rec2[(slot)] = (v2u){p.rng.ctr, out_at};                                                                                       \
   }
 #define POOL_LOAD(c, slot, with_hit)                                                                                                    \
   {                                                                                                                                     \
     c.r0 = rec4[0 * SOL_WG + (slot)]; c.r1 = rec4[1 * SOL_WG + (slot)]; c.r2 = rec4[2 * SOL_WG + (slot)]; c.r3 = rec4[3 * SOL_WG + (slot)];  \
-    if (with_hit) c.r4 = rec4[4 * SOL_WG + (slot)];                                                                                     \
+    c.r4 = rec4[4 * SOL_WG + (slot)];                                                                                                   \
     c.r5 = rec2[(slot)];                                                                                                                \
   }
 #define POOL_ADOPT(c)                                                                                                                   \
@@ -142,7 +143,7 @@ sol_render_pool4_kernel(const DevScene* __restrict__ Sp, const RenderParams P, f
     p.depth = c.r1.w & 0x7FFFFFFFu; p.pdf_seen = (c.r1.w >> 31) != 0u;                                                                  \
     p.A = mk3(__uint_as_float(c.r2.x), __uint_as_float(c.r2.y), __uint_as_float(c.r2.z)); p.rng.k0 = c.r2.w;                            \
     p.C = mk3(__uint_as_float(c.r3.x), __uint_as_float(c.r3.y), __uint_as_float(c.r3.z)); p.rng.k1 = c.r3.w;                            \
-    p.rng.ctr = c.r5.x; out_at = c.r5.y;                                                                                                \
+    p.rng.ctr = c.r5.x; out_at = c.r5.y; p.from = c.r4.x; /* (of a ray; a hit's is set when it is shaded) */                          \
   }
 
   // The pool starts full: every lane makes one context and parks it as a ready ray in its own slot.
@@ -202,7 +203,7 @@ sol_render_pool4_kernel(const DevScene* __restrict__ Sp, const RenderParams P, f
         }
         POOL_ADOPT(c)
         t.o = p.o; t.d = p.d;
-        t.h.t = __uint_as_float(c.r4.x); t.h.ref = c.r4.y; t.h.dfs = 0u; t.h.u = __uint_as_float(c.r4.z); t.h.v = __uint_as_float(c.r4.w);
+        t.h.t = __uint_as_float(c.r4.x); t.h.ref = c.r4.y; t.h.dfs = SOL_DFS_UNKNOWN; t.h.u = __uint_as_float(c.r4.z); t.h.v = __uint_as_float(c.r4.w);
         t.cur = REF_DONE;
         have = true;
         in_flight = true;
@@ -266,6 +267,13 @@ sol_render_pool4_kernel(const DevScene* __restrict__ Sp, const RenderParams P, f
         if (n_act == 0u) break;  // (nothing runs and nothing to service: the wave is done - the outer loop's test ends it)
       }
       trav_step_wave<COUNT, MEDIUM, STRICT, true>(S, t, act, st, p.rng, p.depth, cnt);
+      // (rule 8, sol_path.h) a finished search whose closest hit is the flat primitive the ray left: searched again behind that hit
+      if (act && t.cur == REF_DONE && sol_self_hit(p.from, t.h)) {
+        const float bt = t.bt;
+        const uint32_t bdfs = t.bdfs;
+        trav_begin<true>(t, t.o, t.d, sol_behind(t.h.t), inf, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
+        t.bt = bt; t.bdfs = bdfs;
+      }
       if (COUNT && act && t.cur == REF_DONE) cnt.rays++;
       // (STRICT) a finished search whose closest hit is a triangle the consistency rule refuses searches again, behind that hit
       if (STRICT && act && t.cur == REF_DONE) trav_accept_or_restart(S, t, st);

@@ -54,14 +54,24 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
   t.cur = REF_DONE;
   uint32_t item_rays0 = 0;  // (counted builds) ray count when the lane took its item
   __shared__ uint32_t reservoir[SOL_WG / 64][2];  // per wave: next reserved item, end of the reservation
+  __shared__ uint32_t from_lds[MEDIUM ? SOL_WG : 1];  // (MEDIUM kernels: Path::from of the ray being searched, below)
   if (lane == 0) { reservoir[tid >> 6][0] = 0u; reservoir[tid >> 6][1] = 0u; }
 
   for (;;) {
     // ---- lanes whose search is over: shade the vertex, then start the next ray of the path / sample / item ----
     // (STRICT) a finished search whose closest hit is a triangle the consistency rule refuses: the lane searches again, behind that hit
-    if (STRICT && t.cur == REF_DONE && in_flight) trav_accept_or_restart(S, t, st);
+    // (rule 8) a finished search whose closest hit is the flat primitive the ray had just left is not shaded: the same ray is searched again behind
+    // that hit (through the one trav_begin at the end of this block: a second call site cost the MEDIUM kernels 28 spilled registers)
+    // (MEDIUM kernels sit at the 128-register limit: Path::from waits in LDS while the ray is searched - one dword per lane, written when a ray is made, read
+    // when its search is over - instead of costing 26 spilled registers)
+    const bool again = t.cur == REF_DONE && in_flight && sol_self_hit(MEDIUM ? from_lds[tid] : p.from, t.h);
+    if (STRICT && !again && t.cur == REF_DONE && in_flight) trav_accept_or_restart(S, t, st);
     if (t.cur == REF_DONE) {
-      if (in_flight) {
+      float tmin = RAY_MIN_F;
+      if (again) {
+        p.o = t.o; p.d = t.d;
+        tmin = sol_behind(t.h.t);
+      } else if (in_flight) {
         in_flight = false;
         if (COUNT) cnt.rays++;
         p.o = t.o; p.d = t.d;  // (the ray lives in the search state while it is traced)
@@ -89,7 +99,7 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
       // aligned 8x8 pixel block of one chunk) with ONE returning atomic; lanes take consecutive items from it by popcount
       // prefix. The wave thus waits for the global counter (1-3 us under load, ~88 dequeues/us per address) once per 64
       // items instead of once per service pass.
-      if (!have_item) {
+      if (!again && !have_item) {
         const unsigned long long need = sol_ballot(true);
         const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
         const uint32_t n_need = (uint32_t)__popcll(need), my = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
@@ -128,13 +138,17 @@ sol_render_kernel(const DevScene* __restrict__ Sp, const RenderParams P, float* 
         alive = false;
         if (COUNT) item_rays0 = cnt.rays;
       }
-      if (!alive) {
+      if (!again && !alive) {
         phase_tick<COUNT>(cnt, 2);
         generate_path<COUNT>(S, P.seed_lo, P.seed_hi, it.px, it.py, s, p, cnt);
         alive = true;
       }
       // world.hit(ray, RAY_INTERVAL) (src/renderer/mod.rs:165)
-      trav_begin<true>(t, p.o, p.d, RAY_MIN_F, inf, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
+      if (MEDIUM && !again) from_lds[tid] = p.from;  // (of the ray made above: scattered by shade_vertex, or a camera ray)
+      const float bt = t.bt;
+      const uint32_t bdfs = t.bdfs;
+      trav_begin<true>(t, p.o, p.d, tmin, inf, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
+      if (STRICT && again) { t.bt = bt; t.bdfs = bdfs; }  // (a bound the needle rule had set for this ray stays)
       in_flight = true;
     }
     // ---- search: one step per turn for every lane that has one. The wave leaves for the shading block when too few of
@@ -232,7 +246,7 @@ sol_debug_path_kernel(const DevScene S, const RenderParams P, uint32_t px, uint3
   uint32_t row = 0;
   for (;;) {
     Hit h;
-    closest_hit<false, MEDIUM>(S, p.o, p.d, RAY_MIN_F, inf, h, st, 0, p.rng, p.depth, cnt);
+    closest_hit<false, MEDIUM>(S, p.o, p.d, RAY_MIN_F, inf, h, st, 0, p.rng, p.depth, cnt, p.from);
     if (row + 1 < max_rows) {
       float* o = out + (size_t)row * 12;
       o[0] = p.o.x; o[1] = p.o.y; o[2] = p.o.z; o[3] = p.d.x; o[4] = p.d.y; o[5] = p.d.z; o[6] = h.t;

@@ -676,7 +676,8 @@ DEV bool trav_accept_or_restart(const DevScene& S, Trav& t, const Stack& st) {
   if (ok) return true;
   const float bt = t.h.t;
   const uint32_t bdfs = t.h.dfs;
-  trav_begin<true>(t, t.o, t.d, RAY_MIN_F, __builtin_huge_valf(), S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
+  // (the lower end of the interval stays what it was: RAY_MIN, or the bound of rule 8 - sol_path.h, sol_self_hit)
+  trav_begin<true>(t, t.o, t.d, t.tmin, __builtin_huge_valf(), S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
   t.bt = bt;
   t.bdfs = bdfs;
   return false;
@@ -685,11 +686,18 @@ DEV bool trav_accept_or_restart(const DevScene& S, Trav& t, const Stack& st) {
 // Run-to-completion form of a world search (strict: the scene has needle triangles - the run-time form of the kernels' STRICT).
 template <bool COUNT, bool MEDIUM>
 DEV void closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, Hit& h, const Stack& st, int sp_base, const Rng& rng,
-                     uint32_t depth, Counters& cnt) {
+                     uint32_t depth, Counters& cnt, uint32_t from = 0u) {
   Trav t;
   trav_begin<true>(t, o, d, tmin, tmax, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, sp_base);
   for (int guard = 0; guard < 64; ++guard) {
     while (t.cur != REF_DONE) trav_step<COUNT, MEDIUM, true>(S, t, st, rng, depth, cnt);
+    if (from != 0u && (0x80000000u | t.h.dfs) == from && SOL_REF_KIND(t.h.ref) != SOL_REF_NONE) {  // (fp32 rule 8, sol_path.h sol_self_hit: searched again behind that hit)
+      const float bt = t.bt;
+      const uint32_t bdfs = t.bdfs;
+      trav_begin<true>(t, o, d, __uint_as_float(__float_as_uint(t.h.t) + 1u), tmax, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, sp_base);
+      t.bt = bt; t.bdfs = bdfs;  // (a bound the needle rule had set stays)
+      continue;
+    }
     if (!(S.tri_delta > 0.0f) || trav_accept_or_restart(S, t, st)) break;
   }
   h = t.h;

@@ -106,7 +106,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
       if (has_item && alive) {  // the search of this path's ray has finished: shade it
         const float4 r6 = rec[6 * NS + sl];
         Hit h;
-        h.t = r6.x; h.ref = __float_as_uint(r6.y); h.dfs = 0; h.u = r6.z; h.v = r6.w;
+        h.t = r6.x; h.ref = __float_as_uint(r6.y); h.dfs = SOL_DFS_UNKNOWN; h.u = r6.z; h.v = r6.w;
         f3 c;
         if (shade_vertex<COUNT>(S, p, h, c, cnt)) {
           sum = sum + c;  // add_row_data (src/renderer/mod.rs:361-365): sums, not means, in sample order
@@ -152,6 +152,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
         rec[4 * NS + sl] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(p.rng.ctr));
         rec[5 * NS + sl] = make_float4(__uint_as_float(it.px | (it.py << 16)), __uint_as_float(it.slot), __uint_as_float(it.chunk),
                                        __uint_as_float(s));
+        rec[6 * NS + sl] = make_float4(0.f, __uint_as_float(p.from), 0.f, 0.f);  // (rule 8: Path::from rides in the hit record until the ray is traced)
       } else if (flags & PF_ITEM) {
         rec[1 * NS + sl] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -165,7 +166,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
     // ======== stage B: intersect the queued rays; idle lanes are refilled from the queue ========
     uint32_t head = 0;  // wave-uniform
     bool have = false;
-    uint32_t my_slot = 0;
+    uint32_t my_slot = 0, my_from = 0;
     Trav t;
     t.cur = REF_DONE;
     Rng rng_medium = {0, 0, 0};
@@ -186,6 +187,7 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
             }
             trav_begin<true>(t, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), RAY_MIN_F, inf, S.wroot, S.rxmin, S.rxmax, S.rymin,
                        S.rymax, S.rzmin, S.rzmax, 0);
+            my_from = __float_as_uint(rec[6 * NS + my_slot].y);
             have = true;
           }
         }
@@ -194,7 +196,9 @@ sol_render_pool_kernel(const DevScene S, const RenderParams P, float* __restrict
       if (sol_ballot(have) == 0ull) break;  // every queued ray has been searched
       if (have) {
         for (int k = 0; k < SOL_TRAV_BURST && t.cur != REF_DONE; ++k) trav_step<COUNT, MEDIUM>(S, t, st, rng_medium, depth_medium, cnt);
-        if (t.cur == REF_DONE) {
+        if (t.cur == REF_DONE && sol_self_hit(my_from, t.h)) {  // (rule 8, sol_path.h: searched again behind the primitive the ray left)
+          trav_begin<true>(t, t.o, t.d, sol_behind(t.h.t), inf, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
+        } else if (t.cur == REF_DONE) {
           rec[6 * NS + my_slot] = make_float4(t.h.t, __uint_as_float(t.h.ref), t.h.u, t.h.v);
           if (COUNT) cnt.rays++;
           have = false;
@@ -275,7 +279,7 @@ sol_wf_shade_kernel(const DevScene S, const RenderParams P, float* __restrict__ 
   if (has_item && alive) {  // the search of this path's ray has finished: shade it
     const float4 r6 = rec[6 * NS + sl];
     Hit h;
-    h.t = r6.x; h.ref = __float_as_uint(r6.y); h.dfs = 0; h.u = r6.z; h.v = r6.w;
+    h.t = r6.x; h.ref = __float_as_uint(r6.y); h.dfs = SOL_DFS_UNKNOWN; h.u = r6.z; h.v = r6.w;
     f3 c;
     if (shade_vertex<COUNT>(S, p, h, c, cnt)) {
       sum = sum + c;  // add_row_data (src/renderer/mod.rs:361-365): sums, not means, in sample order
@@ -336,6 +340,7 @@ sol_wf_shade_kernel(const DevScene S, const RenderParams P, float* __restrict__ 
     rec[4 * NS + sl] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(p.rng.ctr));
     rec[5 * NS + sl] = make_float4(__uint_as_float(it.px | (it.py << 16)), __uint_as_float(it.slot), __uint_as_float(it.chunk),
                                    __uint_as_float(s));
+    rec[6 * NS + sl] = make_float4(0.f, __uint_as_float(p.from), 0.f, 0.f);  // (rule 8: Path::from rides in the hit record until the ray is traced)
   } else if (flags & PF_ITEM) {
     rec[1 * NS + sl] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -390,7 +395,7 @@ sol_wf_trace_kernel(const DevScene S, const RenderParams P, WfCounters* __restri
   uint32_t next_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (SOL_WG / 64) + (tid >> 6)));
   bool dry = false;  // the whole pool has been handed out
   bool have = false;
-  uint32_t my_slot = 0;
+  uint32_t my_slot = 0, my_from = 0;
   Trav t;
   t.cur = REF_DONE;
   Rng rng_medium = {0, 0, 0};
@@ -433,6 +438,7 @@ sol_wf_trace_kernel(const DevScene S, const RenderParams P, WfCounters* __restri
           }
           trav_begin<true>(t, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), RAY_MIN_F, inf, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax,
                      S.rzmin, S.rzmax, 0);
+          my_from = __float_as_uint(rec[6 * NS + my_slot].y);
           have = true;
           need = false;
         }
@@ -449,7 +455,9 @@ sol_wf_trace_kernel(const DevScene S, const RenderParams P, WfCounters* __restri
     }
     if (have) {
       for (int k = 0; k < SOL_TRAV_BURST && t.cur != REF_DONE; ++k) trav_step<COUNT, MEDIUM>(S, t, st, rng_medium, depth_medium, cnt);
-      if (t.cur == REF_DONE) {
+      if (t.cur == REF_DONE && sol_self_hit(my_from, t.h)) {  // (rule 8, sol_path.h: searched again behind the primitive the ray left)
+        trav_begin<true>(t, t.o, t.d, sol_behind(t.h.t), inf, S.wroot, S.rxmin, S.rxmax, S.rymin, S.rymax, S.rzmin, S.rzmax, 0);
+      } else if (t.cur == REF_DONE) {
         rec[6 * NS + my_slot] = make_float4(t.h.t, __uint_as_float(t.h.ref), t.h.u, t.h.v);
         if (COUNT) cnt.rays++;
         have = false;

@@ -160,6 +160,29 @@ def test_quad_hit_points_lie_on_the_plane():
     assert abs(sa["live_rays"] - sb["live_rays"]) < 2e-5 * sb["live_rays"]
 
 
+def test_a_ray_does_not_hit_the_flat_primitive_it_leaves():
+    """Eighth fp32-only rule, found by the 1024-spp run of the device-against-f64 gate (profiles/r05_gpu_vs_f64.txt: C1's crop z = -4.9 with a relative
+    difference of -1.4e-5): with the hit point back on its plane (rule 7) the start of a scattered ray is still a few 1e-5 off it at coordinates of hundreds,
+    and a GRAZING ray (|n.d| of a few per cent) finds the plane again at t just above RAY_MIN = 1e-3: the path enters the box it had just left and ends
+    black - 124 of 16.7 M samples, against 5 the other way. A line meets a plane once: the reference's f64 puts that second "hit" at t ~ 1e-11 and never
+    counts it. Sample by sample: where does the float oracle return black while the double one returns light, and where the reverse?"""
+    from solstrale_amd import scenes
+    sc = scenes.cornell_box(RenderConfig(400, 400, 1))
+    x0, y0, x1, y1 = rect = (60, 120, 188, 248)
+    dark = bright = 0
+    total = 0.0
+    for s in range(256):
+        a, _ = orc.render(sc, s, 1, pu.SEED, real=orc.ORC_F32, rect=rect)
+        b, _ = orc.render(sc, s, 1, pu.SEED, real=orc.ORC_F64, rect=rect)
+        a, b = a[y0:y1, x0:x1].astype(np.float64).sum(axis=-1), b[y0:y1, x0:x1].sum(axis=-1)
+        dark += int(((a < 1e-6) & (b > 1e-3)).sum())
+        bright += int(((b < 1e-6) & (a > 1e-3)).sum())
+        total += float((a - b).sum())
+    # before the rule (1024 samples of this crop): 124 dark against 5 bright, summed difference -73.8; with it 9 against 5, -2.2 - what rounding apart at an edge makes
+    assert dark <= 8 and abs(dark - bright) <= 6, (dark, bright)
+    assert abs(total) < 4.0, total
+
+
 def test_spheres_through_a_long_lens():
     """Sixth fp32-only rule: the sphere test takes its discriminant from the distance of the centre to the ray and its roots without
     cancellation. With the reference's formula in single precision the random scenes seen from 100 times the distance (objects of size 1
