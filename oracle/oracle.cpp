@@ -23,7 +23,10 @@
 //   * Blend's normal-choice draw (src/material/mod.rs:438-444) and the normal-map fetch are applied to the
 //     closest hit only instead of every candidate (independent draws: same distribution);
 //   * ConstantMedium's draws come from a sub-stream keyed by (path, depth, medium) so that they do not depend on
-//     the order in which the tree is searched.
+//     the order in which the tree is searched;
+//   * the FLOAT instantiation alone carries the eight fp32-only rules of DESIGN.md 4 (`sizeof(R) == 4` branches: box pad, sphere
+//     roots in the sphere's box, needle triangles, rotated triangle records, sphere / quad hit points back on their surface, the
+//     cancellation-free sphere test, no hit on the flat primitive a ray leaves); the double instantiation is the reference's lines.
 //
 // Build: see oracle/Makefile (g++ -O2 -ffp-contract=off: no FMA contraction, so float results are the plain
 // IEEE sequence the device code reproduces).
